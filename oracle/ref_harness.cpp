@@ -1,0 +1,302 @@
+// TEST INFRASTRUCTURE ONLY - flat-array (ctypes-friendly) driver over the *reference's own* structs and functions.
+// Built together with oracle/ref_shim.cpp and the reference sources into oracle/_ref/libtfhe_ref.so, in the
+// authoring container only (the reference does not travel to the GPU box).  Used by oracle/gen_golden.py to
+// produce tests/golden/*.npz and by tests/test_oracle_vs_ref.py to pin oracle/tfhe_oracle.c bit-for-bit.
+//
+// Flat layouts (all little-endian, C order) - identical to include/tfhe_hip.h:
+//   LWE_n sample      int32[n+1]            = a[0..n-1], b               (n = 630)
+//   LWE_N sample      int32[N+1]            = a[0..N-1], b               (N = 1024, extracted)
+//   TLWE sample       int32[2][N]           = a, b
+//   bk (coef domain)  int32[n][kpl][2][N]   = bk[i].all_sample[p].a[c]   (reference tfhe_io.cpp:899-905 order)
+//   bkFFT             double[n][kpl][2][N/2][2]  = bkFFT[i].all_samples[p].a[c].coefsC[f] (re,im)
+//   ks                int32[N][t][base][n+1]     = ks[i][j][d] as a[0..n-1], b (reference tfhe_io.cpp:777-784)
+#include <cstring>
+#include <cstdlib>
+#include "tfhe.h"
+#include "fpga.h"
+
+extern "C" void ref_shim_MuxRotate_FFT(TLweSample *, const TLweSample *, const TGswSampleFFT *, const int32_t,
+                                       const TGswParams *);
+
+static TFheGateBootstrappingParameterSet *g_params = nullptr;
+static TFheGateBootstrappingSecretKeySet *g_keys = nullptr;
+
+static const int32_t n_ = Value_n, N_ = Value_N, kpl_ = Value_kpl, t_ = 8, base_ = 4;
+
+static void ensure_params() {
+    if (!g_params) g_params = new_default_gate_bootstrapping_parameters(110);
+}
+
+static void to_sample(LweSample *s, const int32_t *flat, int32_t n) {
+    memcpy(s->a, flat, sizeof(int32_t) * n);
+    s->b = flat[n];
+    s->current_variance = 0.;
+}
+static void from_sample(int32_t *flat, const LweSample *s, int32_t n) {
+    memcpy(flat, s->a, sizeof(int32_t) * n);
+    flat[n] = s->b;
+}
+static void to_tlwe(TLweSample *s, const int32_t *flat) {
+    for (int c = 0; c < 2; c++) memcpy(s->a[c].coefsT, flat + c * N_, sizeof(int32_t) * N_);
+    s->current_variance = 0.;
+}
+static void from_tlwe(int32_t *flat, const TLweSample *s) {
+    for (int c = 0; c < 2; c++) memcpy(flat + c * N_, s->a[c].coefsT, sizeof(int32_t) * N_);
+}
+
+extern "C" {
+
+void ref_get_sizes(int32_t *out) {  // n, N, k, l, Bgbit, kpl, t, basebit
+    ensure_params();
+    out[0] = g_params->in_out_params->n;
+    out[1] = g_params->tgsw_params->tlwe_params->N;
+    out[2] = g_params->tgsw_params->tlwe_params->k;
+    out[3] = g_params->tgsw_params->l;
+    out[4] = g_params->tgsw_params->Bgbit;
+    out[5] = g_params->tgsw_params->kpl;
+    out[6] = g_params->ks_t;
+    out[7] = g_params->ks_basebit;
+}
+
+void ref_get_trig_tables(double *rev, double *dir) {  // 4088 doubles each (tfhe_core.h:26,93)
+    memcpy(rev, trig_table_reverse, sizeof(trig_table_reverse));
+    memcpy(dir, trig_table_direct, sizeof(trig_table_direct));
+}
+int32_t ref_trig_table_len() { return (int32_t) (sizeof(trig_table_reverse) / sizeof(double)); }
+void ref_get_bit_reversed(int32_t *out) {
+    for (int i = 0; i < Value_2N; i++) out[i] = (int32_t) bit_reversed[i];
+}
+
+// reference key generation (tfhe_gate_bootstrapping.cpp:97-108) from the reference's own RNG
+void ref_keygen(uint32_t seed) {
+    ensure_params();
+    if (g_keys) delete_gate_bootstrapping_secret_keyset(g_keys);
+    tfhe_random_generator_setSeed(&seed, 1);
+    g_keys = new_random_gate_bootstrapping_secret_keyset(g_params);
+}
+
+void ref_seed(uint32_t seed) { tfhe_random_generator_setSeed(&seed, 1); }
+
+// install keys produced elsewhere (the build's portable client keygen); bkFFT is computed by the reference
+// (init_LweBootstrappingKeyFFT, lwe-bootstrapping-functions-fft.cpp:24-53)
+void ref_set_keys(const int32_t *lwe_key, const int32_t *tlwe_key, const int32_t *bk_coef, const int32_t *ks) {
+    ensure_params();
+    if (g_keys) delete_gate_bootstrapping_secret_keyset(g_keys);
+    LweKey *lk = new_LweKey(g_params->in_out_params);
+    memcpy(lk->key, lwe_key, sizeof(int32_t) * n_);
+    TGswKey *gk = new_TGswKey(g_params->tgsw_params);
+    memcpy(gk->tlwe_key.key[0].coefs, tlwe_key, sizeof(int32_t) * N_);
+    LweBootstrappingKey *bk = new_LweBootstrappingKey(g_params->ks_t, g_params->ks_basebit, g_params->in_out_params,
+                                                      g_params->tgsw_params);
+    for (int i = 0; i < n_; i++)
+        for (int p = 0; p < kpl_; p++) {
+            for (int c = 0; c < 2; c++)
+                memcpy(bk->bk[i].all_sample[p].a[c].coefsT, bk_coef + (((size_t) i * kpl_ + p) * 2 + c) * N_,
+                       sizeof(int32_t) * N_);
+            bk->bk[i].all_sample[p].current_variance = 0.;
+        }
+    for (int i = 0; i < N_; i++)
+        for (int j = 0; j < t_; j++)
+            for (int d = 0; d < base_; d++)
+                to_sample(&bk->ks->ks[i][j][d], ks + (((size_t) i * t_ + j) * base_ + d) * (n_ + 1), n_);
+    LweBootstrappingKeyFFT *bkFFT = new_LweBootstrappingKeyFFT(bk);
+    g_keys = new TFheGateBootstrappingSecretKeySet(g_params, bk, bkFFT, lk, gk);
+}
+
+void ref_get_keys(int32_t *lwe_key, int32_t *tlwe_key, int32_t *bk_coef, int32_t *ks) {
+    memcpy(lwe_key, g_keys->lwe_key->key, sizeof(int32_t) * n_);
+    memcpy(tlwe_key, g_keys->tgsw_key->tlwe_key.key[0].coefs, sizeof(int32_t) * N_);
+    const LweBootstrappingKey *bk = g_keys->cloud.bk;
+    for (int i = 0; i < n_; i++)
+        for (int p = 0; p < kpl_; p++)
+            for (int c = 0; c < 2; c++)
+                memcpy(bk_coef + (((size_t) i * kpl_ + p) * 2 + c) * N_, bk->bk[i].all_sample[p].a[c].coefsT,
+                       sizeof(int32_t) * N_);
+    for (int i = 0; i < N_; i++)
+        for (int j = 0; j < t_; j++)
+            for (int d = 0; d < base_; d++)
+                from_sample(ks + (((size_t) i * t_ + j) * base_ + d) * (n_ + 1), &bk->ks->ks[i][j][d], n_);
+}
+
+void ref_get_bkfft(double *out) {
+    const TGswSampleFFT *b = g_keys->cloud.bkFFT->bkFFT;
+    for (int i = 0; i < n_; i++)
+        for (int p = 0; p < kpl_; p++)
+            for (int c = 0; c < 2; c++)
+                memcpy(out + (((size_t) i * kpl_ + p) * 2 + c) * N_, b[i].all_samples[p].a[c].coefsC,
+                       sizeof(double) * N_);
+}
+
+// ---- client side: bootsSymEncrypt / bootsSymDecrypt / lwePhase (tfhe_gate_bootstrapping.cpp:154-165) ----
+void ref_encrypt(int32_t *out, int32_t bit) {
+    LweSample *s = new_LweSample(g_params->in_out_params);
+    bootsSymEncrypt(s, bit, g_keys);
+    from_sample(out, s, n_);
+    delete_LweSample(s);
+}
+int32_t ref_phase(const int32_t *ct) {
+    LweSample *s = new_LweSample(g_params->in_out_params);
+    to_sample(s, ct, n_);
+    int32_t r = lwePhase(s, g_keys->lwe_key);
+    delete_LweSample(s);
+    return r;
+}
+int32_t ref_decrypt(const int32_t *ct) { return ref_phase(ct) > 0 ? 1 : 0; }
+
+// ---- gates (boot-gates.cpp).  gate ids follow include/tfhe_hip.h ----
+void ref_gate(int32_t gate, int32_t *out, const int32_t *a, const int32_t *b, const int32_t *c) {
+    const LweParams *p = g_params->in_out_params;
+    LweSample *r = new_LweSample(p), *sa = new_LweSample(p), *sb = new_LweSample(p), *sc = new_LweSample(p);
+    if (a) to_sample(sa, a, n_);
+    if (b) to_sample(sb, b, n_);
+    if (c) to_sample(sc, c, n_);
+    const TFheGateBootstrappingCloudKeySet *bk = &g_keys->cloud;
+    switch (gate) {
+        case 0: bootsNAND(r, sa, sb, bk); break;
+        case 1: bootsOR(r, sa, sb, bk); break;
+        case 2: bootsAND(r, sa, sb, bk); break;
+        case 3: bootsXOR(r, sa, sb, bk); break;
+        case 4: bootsXNOR(r, sa, sb, bk); break;
+        case 5: bootsNOR(r, sa, sb, bk); break;
+        case 6: bootsANDNY(r, sa, sb, bk); break;
+        case 7: bootsANDYN(r, sa, sb, bk); break;
+        case 8: bootsORNY(r, sa, sb, bk); break;
+        case 9: bootsORYN(r, sa, sb, bk); break;
+        case 10: bootsMUX(r, sa, sb, sc, bk); break;
+        case 11: bootsNOT(r, sa, bk); break;
+        case 12: bootsCOPY(r, sa, bk); break;
+        case 13: bootsCONSTANT(r, 1, bk); break;
+        case 14: bootsCONSTANT(r, 0, bk); break;
+        default: abort();
+    }
+    from_sample(out, r, n_);
+    delete_LweSample(sc); delete_LweSample(sb); delete_LweSample(sa); delete_LweSample(r);
+}
+
+// ---- bootstrapping stages (lwe-bootstrapping-functions-fft.cpp, lwe-keyswitch-functions.cpp) ----
+void ref_bootstrap_woKS(int32_t *out /*N+1*/, const int32_t *in /*n+1*/, int32_t mu) {
+    LweSample *x = new_LweSample(g_params->in_out_params);
+    LweSample *u = new_LweSample(&g_params->tgsw_params->tlwe_params->extracted_lweparams);
+    to_sample(x, in, n_);
+    tfhe_bootstrap_woKS_FFT(u, g_keys->cloud.bkFFT, mu, x);
+    from_sample(out, u, N_);
+    delete_LweSample(u); delete_LweSample(x);
+}
+void ref_bootstrap(int32_t *out /*n+1*/, const int32_t *in /*n+1*/, int32_t mu) {
+    LweSample *x = new_LweSample(g_params->in_out_params);
+    LweSample *r = new_LweSample(g_params->in_out_params);
+    to_sample(x, in, n_);
+    tfhe_bootstrap_FFT(r, g_keys->cloud.bkFFT, mu, x);
+    from_sample(out, r, n_);
+    delete_LweSample(r); delete_LweSample(x);
+}
+void ref_keyswitch(int32_t *out /*n+1*/, const int32_t *in /*N+1*/) {
+    LweSample *u = new_LweSample(&g_params->tgsw_params->tlwe_params->extracted_lweparams);
+    LweSample *r = new_LweSample(g_params->in_out_params);
+    to_sample(u, in, N_);
+    lweKeySwitch(r, g_keys->cloud.bkFFT->ks, u);
+    from_sample(out, r, n_);
+    delete_LweSample(r); delete_LweSample(u);
+}
+void ref_blind_rotate(int32_t *acc /*[2][N] in/out*/, const int32_t *bara /*n*/) {
+    TLweSample *a = new_TLweSample(g_params->tgsw_params->tlwe_params);
+    to_tlwe(a, acc);
+    tfhe_blindRotate_FFT(a, g_keys->cloud.bkFFT->bkFFT, bara, n_, g_params->tgsw_params);
+    from_tlwe(acc, a);
+    delete_TLweSample(a);
+}
+void ref_mux_rotate(int32_t *out /*[2][N]*/, const int32_t *acc /*[2][N]*/, int32_t i, int32_t barai) {
+    TLweSample *a = new_TLweSample(g_params->tgsw_params->tlwe_params);
+    TLweSample *r = new_TLweSample(g_params->tgsw_params->tlwe_params);
+    to_tlwe(a, acc);
+    ref_shim_MuxRotate_FFT(r, a, g_keys->cloud.bkFFT->bkFFT + i, barai, g_params->tgsw_params);
+    from_tlwe(out, r);
+    delete_TLweSample(r); delete_TLweSample(a);
+}
+void ref_extern_mul(int32_t *acc /*[2][N] in/out*/, int32_t i) {
+    TLweSample *a = new_TLweSample(g_params->tgsw_params->tlwe_params);
+    to_tlwe(a, acc);
+    tGswFFTExternMulToTLwe(a, g_keys->cloud.bkFFT->bkFFT + i, g_params->tgsw_params);
+    from_tlwe(acc, a);
+    delete_TLweSample(a);
+}
+void ref_extract(int32_t *out /*N+1*/, const int32_t *acc /*[2][N]*/) {
+    const TLweParams *tp = g_params->tgsw_params->tlwe_params;
+    TLweSample *a = new_TLweSample(tp);
+    LweSample *u = new_LweSample(&tp->extracted_lweparams);
+    to_tlwe(a, acc);
+    tLweExtractLweSample(u, a, &tp->extracted_lweparams, tp);
+    from_sample(out, u, N_);
+    delete_LweSample(u); delete_TLweSample(a);
+}
+
+// ---- polynomial primitives ----
+void ref_decomp(int32_t *out /*[l][N]*/, const int32_t *poly /*N*/) {
+    ensure_params();
+    IntPolynomial *r = new_IntPolynomial_array(Value_l);
+    TorusPolynomial *p = new_TorusPolynomial();
+    memcpy(p->coefsT, poly, sizeof(int32_t) * N_);
+    tGswTorus32PolynomialDecompH(r, p);
+    for (int q = 0; q < Value_l; q++) memcpy(out + q * N_, r[q].coefs, sizeof(int32_t) * N_);
+    delete_TorusPolynomial(p); delete_IntPolynomial_array(Value_l, r);
+}
+void ref_int_ifft(double *out /*[N/2][2]*/, const int32_t *poly) {
+    IntPolynomial *p = new_IntPolynomial();
+    LagrangeHalfCPolynomial *r = new_LagrangeHalfCPolynomial();
+    memcpy(p->coefs, poly, sizeof(int32_t) * N_);
+    IntPolynomial_ifft(r, p);
+    memcpy(out, r->coefsC, sizeof(double) * N_);
+    delete_LagrangeHalfCPolynomial(r); delete_IntPolynomial(p);
+}
+void ref_torus_ifft(double *out, const int32_t *poly) {
+    TorusPolynomial *p = new_TorusPolynomial();
+    LagrangeHalfCPolynomial *r = new_LagrangeHalfCPolynomial();
+    memcpy(p->coefsT, poly, sizeof(int32_t) * N_);
+    TorusPolynomial_ifft(r, p);
+    memcpy(out, r->coefsC, sizeof(double) * N_);
+    delete_LagrangeHalfCPolynomial(r); delete_TorusPolynomial(p);
+}
+void ref_torus_fft(int32_t *out, const double *spec /*[N/2][2]*/) {
+    TorusPolynomial *p = new_TorusPolynomial();
+    LagrangeHalfCPolynomial *r = new_LagrangeHalfCPolynomial();
+    memcpy(r->coefsC, spec, sizeof(double) * N_);
+    TorusPolynomial_fft(p, r);
+    memcpy(out, p->coefsT, sizeof(int32_t) * N_);
+    delete_LagrangeHalfCPolynomial(r); delete_TorusPolynomial(p);
+}
+void ref_mul_fft(int32_t *out, const int32_t *ipoly, const int32_t *tpoly) {
+    IntPolynomial *a = new_IntPolynomial();
+    TorusPolynomial *b = new_TorusPolynomial(), *r = new_TorusPolynomial();
+    memcpy(a->coefs, ipoly, sizeof(int32_t) * N_);
+    memcpy(b->coefsT, tpoly, sizeof(int32_t) * N_);
+    torusPolynomialMultFFT(r, a, b);
+    memcpy(out, r->coefsT, sizeof(int32_t) * N_);
+    delete_TorusPolynomial(r); delete_TorusPolynomial(b); delete_IntPolynomial(a);
+}
+void ref_mul_naive(int32_t *out, const int32_t *ipoly, const int32_t *tpoly) {
+    IntPolynomial *a = new_IntPolynomial();
+    TorusPolynomial *b = new_TorusPolynomial(), *r = new_TorusPolynomial();
+    memcpy(a->coefs, ipoly, sizeof(int32_t) * N_);
+    memcpy(b->coefsT, tpoly, sizeof(int32_t) * N_);
+    torusPolynomialMultNaive(r, a, b);
+    memcpy(out, r->coefsT, sizeof(int32_t) * N_);
+    delete_TorusPolynomial(r); delete_TorusPolynomial(b); delete_IntPolynomial(a);
+}
+void ref_mul_by_xai(int32_t *out, int32_t a, const int32_t *in) {
+    TorusPolynomial *s = new_TorusPolynomial(), *r = new_TorusPolynomial();
+    memcpy(s->coefsT, in, sizeof(int32_t) * N_);
+    torusPolynomialMulByXai(r, a, s);
+    memcpy(out, r->coefsT, sizeof(int32_t) * N_);
+    delete_TorusPolynomial(r); delete_TorusPolynomial(s);
+}
+void ref_mul_by_xai_minus_one(int32_t *out, int32_t a, const int32_t *in) {
+    TorusPolynomial *s = new_TorusPolynomial(), *r = new_TorusPolynomial();
+    memcpy(s->coefsT, in, sizeof(int32_t) * N_);
+    torusPolynomialMulByXaiMinusOne(r, a, s);
+    memcpy(out, r->coefsT, sizeof(int32_t) * N_);
+    delete_TorusPolynomial(r); delete_TorusPolynomial(s);
+}
+int32_t ref_modswitch_from(int32_t phase, int32_t Msize) { return modSwitchFromTorus32(phase, Msize); }
+int32_t ref_modswitch_to(int32_t mu, int32_t Msize) { return modSwitchToTorus32(mu, Msize); }
+
+}  // extern "C"
