@@ -1,0 +1,134 @@
+/* tfhe_hip.h - C-ABI of the MI355X gate-bootstrapping engine (libtfhe_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of emwjacobson/tfhe (reference under /root/reference, cited as
+ * file:line below).  In the reference the device seam is
+ *     EXPORT void tfhe_blindRotate_FFT(TLweSample*, const TGswSampleFFT*, const int32_t* bara, int32_t n,
+ *                                      const TGswParams*)         src/include/tfhe.h:42,
+ *                                                                 src/libtfhe/lwe-bootstrapping-functions-fft.cpp:89
+ * which flattens the structs into PODs and launches one FPGA kernel per ciphertext (src/kernels/
+ * tfhe_blindRotate_FFT.cpp:36).  Here the seam is batched and widened to everything that runs per gate:
+ * pre-combination, modulus switch, blind rotation, sample extraction and keyswitch.  Plain pointers and sizes
+ * only; all functions return 0 on success and a negative code on error (message: tfhe_hip_last_error()).
+ *
+ * Default parameter set only (reference src/include/tfhe_core.h:13-24, tfhe_gate_bootstrapping.cpp:51-75):
+ *   n = 630, N = 1024, k = 1, l = 3, Bgbit = 7, keyswitch t = 8, basebit = 2.
+ *
+ * Flat layouts (little-endian, C order; Torus32 = int32_t with wrap-around arithmetic):
+ *   LWE_n sample   int32[n+1]  = a[0..n-1], b            (reference struct LweSample, lwesamples.h:9-20)
+ *   LWE_N sample   int32[N+1]  = a[0..N-1], b            (extracted sample, before keyswitch)
+ *   TLWE sample    int32[2][N] = a, b                     (reference TLweSample / TLweSample_FPGA, polynomials.h:45)
+ *   spectrum       double[N/2][2] = LagrangeHalfCPolynomial.coefsC (re,im), P(w^(2i+1)), polynomials.h:32-36
+ *   bk_coef        int32[n][6][2][N]      = bk[i].all_sample[p].a[c].coefsT   (order of tfhe_io.cpp:899-905)
+ *   bkfft          double[n][6][2][N/2][2] = bkFFT[i].all_samples[p].a[c].coefsC
+ *   ks             int32[N][t][4][n+1]    = ks[i][j][d] as a[0..n-1], b       (order of tfhe_io.cpp:777-784)
+ *
+ * Results are bit-identical to the reference CPU path (its own "optim" build flags, no FMA contraction): see
+ * DESIGN.md "Arithmetic contract".
+ */
+#ifndef TFHE_HIP_H
+#define TFHE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFHE_HIP_n 630
+#define TFHE_HIP_N 1024
+#define TFHE_HIP_KPL 6
+#define TFHE_HIP_KS_T 8
+#define TFHE_HIP_KS_BASE 4
+
+/* gate ids; the linear pre-combination of each is the one of reference src/libtfhe/boot-gates.cpp */
+enum tfhe_hip_gate {
+    TFHE_HIP_NAND = 0,   /* boot-gates.cpp:35  */
+    TFHE_HIP_OR = 1,     /* :61  */
+    TFHE_HIP_AND = 2,    /* :87  */
+    TFHE_HIP_XOR = 3,    /* :113 */
+    TFHE_HIP_XNOR = 4,   /* :139 */
+    TFHE_HIP_NOR = 5,    /* :198 */
+    TFHE_HIP_ANDNY = 6,  /* :224 */
+    TFHE_HIP_ANDYN = 7,  /* :250 */
+    TFHE_HIP_ORNY = 8,   /* :276 */
+    TFHE_HIP_ORYN = 9,   /* :302 */
+    TFHE_HIP_MUX = 10,   /* :329 two bootstraps without keyswitch + one keyswitch */
+    TFHE_HIP_NOT = 11,   /* :164 no bootstrap */
+    TFHE_HIP_COPY = 12,  /* :175 no bootstrap */
+    TFHE_HIP_CONST1 = 13,/* :185 bootsCONSTANT(1) */
+    TFHE_HIP_CONST0 = 14 /* :185 bootsCONSTANT(0) */
+};
+
+enum {
+    TFHE_HIP_OK = 0,
+    TFHE_HIP_ERR_ARG = -1,     /* bad argument (null pointer, negative count, unknown gate) */
+    TFHE_HIP_ERR_HIP = -2,     /* a HIP runtime call failed */
+    TFHE_HIP_ERR_NOKEY = -3,   /* keys not loaded */
+    TFHE_HIP_ERR_TABLE = -4    /* twiddle-table self check failed (host libm differs) */
+};
+
+typedef struct tfhe_hip_ctx tfhe_hip_ctx;
+
+/* One context per GPU (and per process in the one-process-per-GPU model).  Replaces the reference's global
+ * `FPGA_Processor fpga` singleton (src/include/fpga.h:13-34, src/libtfhe/fpga.cpp:8-37): owns the stream, the
+ * device copies of the keys and the batch workspaces. */
+int tfhe_hip_create(tfhe_hip_ctx **out, int device);
+void tfhe_hip_destroy(tfhe_hip_ctx *ctx);
+const char *tfhe_hip_last_error(void);
+
+/* Key upload.  Replaces the per-call copy of the whole bkFFT into the OpenCL buffer
+ * (lwe-bootstrapping-functions-fft.cpp:112-133) by a one-time upload.
+ * _coef : takes the coefficient-domain TGSW key and performs tGswToFFTConvert on the GPU
+ *         (init_LweBootstrappingKeyFFT, lwe-bootstrapping-functions-fft.cpp:24-53; tgsw-fft-operations.cpp:52-57)
+ * _fft  : takes an already converted key in the reference's LagrangeHalfC layout.
+ * Host pointers; the caller may free its copies afterwards. */
+int tfhe_hip_load_keys_coef(tfhe_hip_ctx *ctx, const int32_t *bk_coef, const int32_t *ks);
+int tfhe_hip_load_keys_fft(tfhe_hip_ctx *ctx, const double *bkfft, const int32_t *ks);
+/* device copy of the FFT key back in the reference layout (parity check of the conversion) */
+int tfhe_hip_get_bkfft(tfhe_hip_ctx *ctx, double *bkfft_out);
+
+/* ---- batched gates, host buffers in and out (PCIe inclusive) --------------------------------------------------
+ * out[count][n+1]; a,b,c[count][n+1]; b/c may be NULL where the gate does not read them.
+ * Semantics per element = bootsNAND/.../bootsMUX of boot-gates.cpp. */
+int tfhe_hip_gate_batch(tfhe_hip_ctx *ctx, int gate, int32_t *out, const int32_t *a, const int32_t *b,
+                        const int32_t *c, int64_t count);
+/* tfhe_bootstrap_FFT (with_ks != 0, out[count][n+1]; lwe-bootstrapping-functions-fft.cpp:266) or
+ * tfhe_bootstrap_woKS_FFT (with_ks == 0, out[count][N+1]; :222) */
+int tfhe_hip_bootstrap_batch(tfhe_hip_ctx *ctx, int32_t *out, const int32_t *in, int32_t mu, int64_t count,
+                             int with_ks);
+/* lweKeySwitch (lwe-keyswitch-functions.cpp:228): in[count][N+1] -> out[count][n+1] */
+int tfhe_hip_keyswitch_batch(tfhe_hip_ctx *ctx, int32_t *out, const int32_t *in, int64_t count);
+
+/* ---- the same with every buffer already resident in device memory; asynchronous on the context's stream ---- */
+int tfhe_hip_gate_batch_dev(tfhe_hip_ctx *ctx, int gate, int32_t *d_out, const int32_t *d_a, const int32_t *d_b,
+                            const int32_t *d_c, int64_t count);
+int tfhe_hip_bootstrap_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_in, int32_t mu, int64_t count,
+                                 int with_ks);
+int tfhe_hip_keyswitch_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_in, int64_t count);
+int tfhe_hip_sync(tfhe_hip_ctx *ctx);
+/* raw stream handle (hipStream_t) so that callers can record events on the stream the kernels run on */
+void *tfhe_hip_stream(tfhe_hip_ctx *ctx);
+/* device time of the kernels of the most recent *_batch / *_batch_dev call, from HIP events on the stream
+ * (blind rotation incl. pre-combination and extraction; keyswitch).  Synchronises the stream. */
+int tfhe_hip_last_kernel_ms(tfhe_hip_ctx *ctx, float *blind_rotate_ms, float *keyswitch_ms);
+
+/* ---- stage-level entry points (host buffers), for parity tests and the FFT microbench ----------------------- */
+/* tfhe_blindRotate_FFT (the reference seam itself): acc[count][2][N] in/out, bara[count][n] in [0,2N) */
+int tfhe_hip_blind_rotate_batch(tfhe_hip_ctx *ctx, int32_t *acc, const int32_t *bara, int64_t count);
+/* tGswFFTExternMulToTLwe (tgsw-fft-operations.cpp:92): acc[count][2][N] in/out, key_index[count] in [0,n) */
+int tfhe_hip_extern_mul_batch(tfhe_hip_ctx *ctx, int32_t *acc, const int32_t *key_index, int64_t count);
+/* IntPolynomial_ifft / TorusPolynomial_ifft / TorusPolynomial_fft (polynomials.cpp:347,364,378) */
+int tfhe_hip_int_ifft_batch(tfhe_hip_ctx *ctx, double *spectra, const int32_t *polys, int64_t count);
+int tfhe_hip_torus_ifft_batch(tfhe_hip_ctx *ctx, double *spectra, const int32_t *polys, int64_t count);
+int tfhe_hip_torus_fft_batch(tfhe_hip_ctx *ctx, int32_t *polys, const double *spectra, int64_t count);
+/* torusPolynomialMultFFT (polynomials.cpp:241): out = ipoly * tpoly mod X^N+1 */
+int tfhe_hip_negacyclic_mul_batch(tfhe_hip_ctx *ctx, int32_t *out, const int32_t *ipolys, const int32_t *tpolys,
+                                  int64_t count);
+/* device-resident variant used by bench.py's FFT microbench leg */
+int tfhe_hip_negacyclic_mul_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_ipolys,
+                                      const int32_t *d_tpolys, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFHE_HIP_H */

@@ -1,0 +1,157 @@
+"""GPU parity: every C-ABI entry point of libtfhe_hip.so against the oracle, BIT FOR BIT, on seeded inputs.
+
+The oracle (oracle/tfhe_oracle.c) is itself pinned bit-for-bit to the reference (tests/test_oracle_vs_ref.py in the
+authoring container, tests/golden/*.npz elsewhere).  The bar for this whole file is exact equality - spectra as IEEE
+doubles, ciphertexts as int32 - because the kernels perform the reference's floating-point operations one for one
+(DESIGN.md "Arithmetic contract")."""
+import numpy as np
+import pytest
+
+from tfhe_amd import Gate, PARAMS as P
+
+pytestmark = pytest.mark.gpu
+
+
+def test_key_conversion_bit_exact(engine, oracle, okeys):
+    # tGswToFFTConvert on the GPU == reference/oracle conversion (reference lwe-bootstrapping-functions-fft.cpp:47-50)
+    got = engine.get_bkfft()
+    want = oracle.bkfft(okeys)
+    assert np.array_equal(got, want)
+
+
+def test_forward_transforms_bit_exact(engine, oracle):
+    rng = np.random.default_rng(10)
+    ints = rng.integers(-64, 64, (16, P.N)).astype(np.int32)
+    ints[0] = 0
+    ints[1] = 63
+    ints[2] = -64
+    got = engine.int_ifft(ints)
+    for i in range(ints.shape[0]):
+        assert np.array_equal(got[i], oracle.int_ifft(ints[i])), i
+    tor = rng.integers(-2**31, 2**31, (16, P.N)).astype(np.int32)
+    tor[0] = -2**31
+    tor[1] = 2**31 - 1
+    got = engine.torus_ifft(tor)
+    for i in range(tor.shape[0]):
+        assert np.array_equal(got[i], oracle.torus_ifft(tor[i])), i
+
+
+def test_inverse_transform_bit_exact(engine, oracle):
+    rng = np.random.default_rng(11)
+    tor = rng.integers(-2**31, 2**31, (12, P.N)).astype(np.int32)
+    spec = np.stack([oracle.torus_ifft(t) for t in tor]) * rng.integers(1, 90000, (12, 1, 1))
+    spec[0] = 0.0
+    got = engine.torus_fft(spec)
+    for i in range(spec.shape[0]):
+        assert np.array_equal(got[i], oracle.torus_fft(spec[i])), i
+
+
+def test_negacyclic_mul_bit_exact_and_vs_naive(engine, oracle):
+    # distribution of reference src/test/test-multiplication.cpp:41-44; FFT product within 1 LSB of the exact
+    # product (:66-77) and identical to the reference's FFT product
+    rng = np.random.default_rng(12)
+    a = rng.integers(-2 * P.N, 2 * P.N, (24, P.N)).astype(np.int32)
+    b = rng.integers(-2**31, 2**31, (24, P.N)).astype(np.int32)
+    got = engine.negacyclic_mul(a, b)
+    for i in range(a.shape[0]):
+        assert np.array_equal(got[i], oracle.mul_fft(a[i], b[i])), i
+        d = (got[i].astype(np.int64) - oracle.mul_naive(a[i], b[i]).astype(np.int64) + 2**31) % 2**32 - 2**31
+        assert np.abs(d).max() <= 1
+
+
+def test_external_product_bit_exact(engine, oracle, okeys):
+    rng = np.random.default_rng(13)
+    acc = rng.integers(-2**31, 2**31, (8, 2, P.N)).astype(np.int32)
+    idx = np.array([0, 1, 2, 100, 314, 500, 628, 629], np.int32)
+    got = engine.extern_mul_batch(acc, idx)
+    for i in range(8):
+        assert np.array_equal(got[i], oracle.extern_mul(okeys, acc[i], int(idx[i]))), i
+
+
+def test_blind_rotate_seam_bit_exact(engine, oracle, okeys):
+    # the reference's own device seam: tfhe_blindRotate_FFT(accum, bkFFT, bara, n)
+    rng = np.random.default_rng(14)
+    acc = rng.integers(-2**31, 2**31, (3, 2, P.N)).astype(np.int32)
+    bara = rng.integers(0, 2 * P.N, (3, P.n)).astype(np.int32)
+    bara[1, :17] = 0          # the skipped iterations (lwe-bootstrapping-functions-fft.cpp:154)
+    bara[2, ::2] = 2 * P.N - 1
+    got = engine.blind_rotate_batch(acc, bara)
+    for i in range(3):
+        assert np.array_equal(got[i], oracle.blind_rotate(okeys, acc[i], bara[i])), i
+
+
+def test_keyswitch_bit_exact(engine, oracle, okeys):
+    rng = np.random.default_rng(15)
+    for count in (1, 5, 32, 33, 70):      # ragged around the 32-ciphertext tile
+        u = rng.integers(-2**31, 2**31, (count, P.N + 1)).astype(np.int32)
+        u[0, :10] = 0                     # all-zero digits
+        got = engine.keyswitch_batch(u)
+        for i in sorted({0, count // 2, count - 1}):
+            assert np.array_equal(got[i], oracle.keyswitch(okeys, u[i])), (count, i)
+
+
+def test_bootstrap_bit_exact(engine, oracle, okeys, client, keys):
+    bits = np.array([0, 1, 1, 0, 1], np.uint8)
+    x = client.encrypt(keys, bits, seed=21)
+    got_woks = engine.bootstrap_batch(x, with_ks=False)
+    got = engine.bootstrap_batch(x, with_ks=True)
+    for i in range(2):
+        assert np.array_equal(got_woks[i], oracle.bootstrap_woks(okeys, x[i])), i
+        assert np.array_equal(got[i], oracle.bootstrap(okeys, x[i])), i
+    dec, _ = client.decrypt(keys, got)
+    assert np.array_equal(dec, bits)
+    dec, _ = client.decrypt(keys, got_woks, extracted=True)
+    assert np.array_equal(dec, bits)
+
+
+TRUTH = {
+    Gate.NAND: lambda a, b, c: 1 - (a & b), Gate.OR: lambda a, b, c: a | b, Gate.AND: lambda a, b, c: a & b,
+    Gate.XOR: lambda a, b, c: a ^ b, Gate.XNOR: lambda a, b, c: 1 - (a ^ b), Gate.NOR: lambda a, b, c: 1 - (a | b),
+    Gate.ANDNY: lambda a, b, c: (1 - a) & b, Gate.ANDYN: lambda a, b, c: a & (1 - b),
+    Gate.ORNY: lambda a, b, c: (1 - a) | b, Gate.ORYN: lambda a, b, c: a | (1 - b),
+    Gate.MUX: lambda a, b, c: np.where(a == 1, b, c), Gate.NOT: lambda a, b, c: 1 - a, Gate.COPY: lambda a, b, c: a,
+    Gate.CONST1: lambda a, b, c: np.ones_like(a), Gate.CONST0: lambda a, b, c: np.zeros_like(a),
+}
+
+
+@pytest.mark.parametrize("gate", list(Gate))
+def test_every_gate_bit_exact_and_truth_table(gate, engine, oracle, okeys, client, keys):
+    # 8 input combinations = the full truth table of a 3-input gate (reference boots_gates_test.cpp:59-91)
+    a = np.array([0, 1, 0, 1, 0, 1, 0, 1], np.uint8)
+    b = np.array([0, 0, 1, 1, 0, 0, 1, 1], np.uint8)
+    c = np.array([0, 0, 0, 0, 1, 1, 1, 1], np.uint8)
+    ca, cb, cc = client.encrypt(keys, a, 31), client.encrypt(keys, b, 32), client.encrypt(keys, c, 33)
+    got = engine.gate_batch(gate, ca, cb, cc)
+    dec, phases = client.decrypt(keys, got)
+    assert np.array_equal(dec, TRUTH[gate](a.astype(np.int64), b.astype(np.int64), c.astype(np.int64)))
+    ncheck = 8 if gate >= Gate.NOT else 2
+    for i in range(ncheck):
+        assert np.array_equal(got[i], oracle.gate(okeys, gate, ca[i], cb[i], cc[i])), i
+
+
+def test_batch_of_independent_nands_decrypts(engine, client, keys, oracle, okeys):
+    # config "batch of independent bootsNAND gates", reduced; every output must decrypt to NAND and sampled
+    # ciphertexts must equal the oracle's (reference test-gate-bootstrapping.cpp:78-88)
+    rng = np.random.default_rng(40)
+    count = 1000                       # not a multiple of the 4-/8-wave workgroup nor of the keyswitch tile
+    a = rng.integers(0, 2, count).astype(np.uint8)
+    b = rng.integers(0, 2, count).astype(np.uint8)
+    ca, cb = client.encrypt(keys, a, 41), client.encrypt(keys, b, 42)
+    got = engine.gate_batch(Gate.NAND, ca, cb)
+    dec, phases = client.decrypt(keys, got)
+    assert np.array_equal(dec, 1 - (a & b))
+    assert np.abs(np.abs(phases.astype(np.int64)) - (1 << 29)).max() < (1 << 28)   # |phase -+ MU| < 1/16
+    for i in (0, 499, 999):
+        assert np.array_equal(got[i], oracle.gate(okeys, Gate.NAND, ca[i], cb[i])), i
+
+
+def test_empty_batch_and_argument_errors(engine):
+    from tfhe_amd import TfheHipError
+    out = engine.gate_batch(Gate.NAND, np.zeros((0, P.n + 1), np.int32), np.zeros((0, P.n + 1), np.int32))
+    assert out.shape == (0, P.n + 1)
+    with pytest.raises(TfheHipError):
+        engine.gate_batch(99, np.zeros((1, P.n + 1), np.int32), np.zeros((1, P.n + 1), np.int32))
+    with pytest.raises(TfheHipError):
+        engine.gate_batch(Gate.NAND, np.zeros((1, P.n + 1), np.int32), None, count=1)
+    with pytest.raises(TfheHipError):
+        engine.extern_mul_batch(np.zeros((1, 2, P.N), np.int32), np.array([630], np.int32))

@@ -1,0 +1,71 @@
+"""Builds the native pieces in-tree.
+
+  tfhe_amd/libtfhe_hip.so     HIP kernels + C-ABI (include/tfhe_hip.h), cross-compiled for gfx950
+  tfhe_amd/libtfhe_client.so  client-side key generation / encryption (host C)
+  oracle/liboracle.so         CPU restatement of the reference path (test infrastructure)
+  oracle/_ref/libtfhe_ref.so  the reference itself, only where /root/reference exists (authoring container)
+"""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "tfhe_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+REFERENCE = "/root/reference"
+
+
+def _run(cmd, **kw):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, **kw)
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_hip(force=False):
+    out = os.path.join(ROOT, "tfhe_amd", "libtfhe_hip.so")
+    srcs = [os.path.join(CSRC, "tfhe_hip.hip"), os.path.join(CSRC, "br_core.h"),
+            os.path.join(CSRC, "compat_libtfhe.cpp"), os.path.join(ROOT, "include", "tfhe_hip.h"),
+            os.path.join(ROOT, "include", "tfhe_hip_compat.h")]
+    srcs = [s for s in srcs if os.path.exists(s)]
+    if force or _stale(out, srcs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-I" + os.path.join(ROOT, "include"), "-o", out, os.path.join(CSRC, "tfhe_hip.hip")]
+        compat = os.path.join(CSRC, "compat_libtfhe.cpp")
+        if os.path.exists(compat):
+            cmd.append(compat)
+        _run(cmd)
+    return out
+
+
+def build_client(force=False):
+    out = os.path.join(ROOT, "tfhe_amd", "libtfhe_client.so")
+    src = os.path.join(CSRC, "client_keys.c")
+    if force or _stale(out, [src]):
+        _run(["gcc", "-std=gnu11", "-O2", "-fPIC", "-shared", "-o", out, src, "-lpthread"])
+    return out
+
+
+def build_oracle(force=False):
+    args = ["make", "-C", os.path.join(ROOT, "oracle"), "oracle"]
+    if force:
+        args.insert(1, "-B")
+    _run(args)
+    if os.path.isdir(REFERENCE):
+        _run(["make", "-C", os.path.join(ROOT, "oracle"), "-j8", "ref"], stdout=subprocess.DEVNULL,
+             stderr=subprocess.DEVNULL)
+
+
+def build_all(force=False):
+    build_hip(force)
+    build_client(force)
+    build_oracle(force)
+
+
+if __name__ == "__main__":
+    import sys
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,59 @@
+"""Client side (key generation, encryption, decryption): ctypes binding of libtfhe_client.so (csrc/client_keys.c).
+Host CPU code; produces the inputs of the accelerated path in the flat layouts of include/tfhe_hip.h."""
+import ctypes
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from .engine import PARAMS
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtfhe_client.so")
+
+
+@dataclass
+class KeySet:
+    seed: int
+    lwe_key: np.ndarray   # int32[n]      secret
+    tlwe_key: np.ndarray  # int32[N]      secret (= extracted LWE_N key)
+    bk_coef: np.ndarray   # int32[n][6][2][N]   cloud
+    ks: np.ndarray        # int32[N][t][4][n+1] cloud
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class Client:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s not built: run `python -m tfhe_amd.build`" % LIB_PATH)
+        self.lib = ctypes.CDLL(LIB_PATH)
+
+    def keygen(self, seed=42):
+        P = PARAMS
+        lk = np.zeros(P.n, np.int32)
+        tk = np.zeros(P.N, np.int32)
+        bk = np.zeros((P.n, P.kpl, 2, P.N), np.int32)
+        ks = np.zeros((P.N, P.ks_t, P.ks_base, P.n + 1), np.int32)
+        self.lib.tfhe_client_keygen(ctypes.c_uint64(seed), _p(lk), _p(tk), _p(bk), _p(ks))
+        return KeySet(seed, lk, tk, bk, ks)
+
+    def encrypt(self, keys, bits, seed=1):
+        bits = np.ascontiguousarray(bits, dtype=np.uint8).reshape(-1)
+        out = np.zeros((bits.shape[0], PARAMS.n + 1), np.int32)
+        self.lib.tfhe_client_encrypt(ctypes.c_uint64(seed), _p(keys.lwe_key), _p(bits), ctypes.c_int64(bits.shape[0]),
+                                     _p(out))
+        return out
+
+    def decrypt(self, keys, cts, extracted=False):
+        """returns (bits, phases); extracted=True decrypts LWE_N samples under the TLWE key"""
+        key = keys.tlwe_key if extracted else keys.lwe_key
+        n = key.shape[0]
+        cts = np.ascontiguousarray(cts, dtype=np.int32).reshape(-1, n + 1)
+        bits = np.zeros(cts.shape[0], np.uint8)
+        phases = np.zeros(cts.shape[0], np.int32)
+        self.lib.tfhe_client_decrypt(_p(key), ctypes.c_int32(n), _p(cts), ctypes.c_int64(cts.shape[0]), _p(bits),
+                                     _p(phases))
+        return bits, phases

@@ -1,0 +1,319 @@
+// Per-lane building blocks of the blind-rotation kernel (one wavefront = one ciphertext, 64 lanes).
+//
+// Everything here is written as "what lane `lane` of the wave does", with the cross-lane exchanges going through a
+// wave-private LDS scratch area.  The same code is compiled for the GPU (tfhe_hip_kernels.hip) and, for
+// pre-validation without a GPU, for the host (tests/emu/emu_wave.cpp runs the 64 lanes in a loop, phase by phase).
+//
+// ARITHMETIC CONTRACT.  The reference computes its negacyclic transforms with a 2048-point radix-2 FFT
+// (reference src/libtfhe/polynomials.cpp:13-175) on an antisymmetric real extension (:347-362) / on a Hermitian
+// spectrum (:378-393).  In that computation most operands are exact zeros or exact complex conjugates of other
+// operands.  The routines below perform exactly the remaining floating-point operations - the same IEEE-754
+// binary64 multiplications and additions, on the same operands, each rounded on its own (no FMA contraction:
+// this file must be compiled with -ffp-contract=off) - so their results are BIT-IDENTICAL to the reference's:
+//
+//  forward  (IntPolynomial_ifft / TorusPolynomial_ifft): after the size-2 and size-4 merges the 2048 array holds
+//           z_k = p_k + i p_{k+N/2} (k bit-reversed) and conjugates; every later block keeps only odd bins and
+//           is Hermitian, so 512 complex values per level suffice: 9 levels x 256 butterflies
+//               E' = E + w O ,   O' = conj(E - w O)
+//           done in place; the conjugate-mirrored placement of the reference turns into a Gray-code relabelling:
+//           physical slot x holds logical bin igray(x), twiddle index q = 2*igray_k(x mod 2^k) + 1.
+//  inverse  (TorusPolynomial_fft): the even half of the bit-reversed array stays zero, the odd half is a plain
+//           1024-point DIT FFT of c~[m] = C[m] (m<512), conj(C[1023-m]) (m>=512), followed by the last merge
+//           of which only  Re = Wr*cos + Wi*sin  is used, scaled by 2^22 and truncated toward zero (:392).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BRC_HD __host__ __device__ __forceinline__
+#else
+#define BRC_HD inline
+#endif
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace brc {
+
+constexpr int kN = 1024;       // polynomial degree
+constexpr int kNh = 512;       // N/2
+constexpr int kLwe = 630;      // n
+constexpr int kL = 3;          // decomposition length
+constexpr int kKpl = 6;        // (k+1)*l rows
+constexpr int kBgbit = 7;
+constexpr uint32_t kDecompOffset = 2164391936u;  // reference src/include/tfhe_core.h:24
+constexpr int kTwEntries = 2044;                 // sizes 8..2048: sum of size/2
+
+struct alignas(16) c64 {
+    double re, im;
+};
+
+// index of twiddle j of the table for merge size `size` (8..2048): w = cos(2 pi j/size) + i sin(2 pi j/size)
+BRC_HD constexpr int tw_idx(int size, int j) { return size / 2 - 4 + j; }
+
+BRC_HD constexpr int br3(int v) { return ((v & 1) << 2) | (v & 2) | ((v >> 2) & 1); }
+BRC_HD constexpr int br4(int v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v >> 1) & 2) | ((v >> 3) & 1); }
+BRC_HD int br6(int v) { return (br3(v & 7) << 3) | br3((v >> 3) & 7); }
+// inverse Gray code (prefix xor from the top) of a value of up to 16 bits
+BRC_HD constexpr int igray(int u) {
+    u ^= u >> 1;
+    u ^= u >> 2;
+    u ^= u >> 4;
+    u ^= u >> 8;
+    return u;
+}
+BRC_HD constexpr int gray(int u) { return u ^ (u >> 1); }
+
+// ---- LDS scratch swizzles (slot = 16-byte element index inside the wave's 8 KB scratch) -------------------
+// chosen so that the ds_write_b128 / ds_read_b128 of the transposes below are bank-conflict free or 2-way
+BRC_HD int swz(int x) { return x ^ ((x >> 3) & 7) ^ (((x >> 6) & 1) << 3); }
+
+// ---- butterflies ---------------------------------------------------------------------------------------------
+// forward ("reverse" table of the reference, polynomials.cpp:78-85 with s = -sin):
+//   t = (Or*c + Oi*(-s), Oi*c - Or*(-s));  x*(-s) == -(x*s) and a+(-b) == a-b exactly, hence the form below
+BRC_HD void fwd_bf(c64 &E, c64 &O, const c64 w) {
+    const double tr = O.re * w.re - O.im * w.im;
+    const double ti = O.im * w.re + O.re * w.im;
+    const c64 lo = {E.re + tr, E.im + ti};
+    const c64 hi = {E.re - tr, ti - E.im};  // conj(E - t)
+    E = lo;
+    O = hi;
+}
+// inverse ("direct" table, polynomials.cpp:160-167)
+BRC_HD void inv_bf(c64 &E, c64 &O, const c64 w) {
+    const double tr = O.re * w.re + O.im * w.im;
+    const double ti = O.im * w.re - O.re * w.im;
+    const c64 lo = {E.re + tr, E.im + ti};
+    const c64 hi = {E.re - tr, E.im - ti};
+    E = lo;
+    O = hi;
+}
+
+// =================================================================================================================
+// FORWARD TRANSFORM, 512 complex values, 8 per lane.
+//   physical slot x (9 bits).  phase A: lane l, reg r  <-> x = br6(l)<<3 | r      (levels 0..2 on x0..x2)
+//                              phase B: lane l, reg r  <-> x = (l>>3)<<6 | r<<3 | (l&7)   (levels 3..5 on x3..x5)
+//                              phase C: lane l, reg r  <-> x = r<<6 | l            (levels 6..8 on x6..x8)
+//   input of phase A:  v[r] = p[j] + i p[j+512],  j = br9(x) = br3(r)<<6 | l
+//   output of phase C: v[r] = P(omega^(2i+1)),    i = igray(x)         (reference LagrangeHalfC index i)
+// =================================================================================================================
+template <class TW>  // TW: functor (index) -> c64 ; uniform indices
+BRC_HD void fwd_phaseA(c64 (&v)[8], const TW &tw) {
+    const c64 w8 = tw(tw_idx(8, 1));
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) fwd_bf(v[r], v[r + 1], w8);
+    const c64 w16a = tw(tw_idx(16, 1)), w16b = tw(tw_idx(16, 3));
+#pragma unroll
+    for (int g = 0; g < 8; g += 4) {
+        fwd_bf(v[g + 0], v[g + 2], w16a);
+        fwd_bf(v[g + 1], v[g + 3], w16b);
+    }
+    // level 2 (size 32): u = r&3 -> igray = 0,1,3,2 -> q = 1,3,7,5
+    const c64 w32a = tw(tw_idx(32, 1)), w32b = tw(tw_idx(32, 3)), w32c = tw(tw_idx(32, 7)), w32d = tw(tw_idx(32, 5));
+    fwd_bf(v[0], v[4], w32a);
+    fwd_bf(v[1], v[5], w32b);
+    fwd_bf(v[2], v[6], w32c);
+    fwd_bf(v[3], v[7], w32d);
+}
+
+// slot written by lane/reg in phase A layout, read in phase B layout
+BRC_HD int fwd_xA(int lane, int r) { return (br6(lane) << 3) | r; }
+BRC_HD int fwd_xB(int lane, int r) { return ((lane >> 3) << 6) | (r << 3) | (lane & 7); }
+BRC_HD int fwd_xC(int lane, int r) { return (r << 6) | lane; }
+
+template <class TW>  // TW: (index) -> c64, lane-varying indices (LDS table)
+BRC_HD void fwd_phaseB(c64 (&v)[8], int lane, const TW &tw) {
+    const int g3 = igray(lane & 7);  // igray of x2x1x0
+    {   // level 3, size 64: q = 2*g3+1
+        const c64 w = tw(tw_idx(64, 2 * g3 + 1));
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) fwd_bf(v[r], v[r + 1], w);
+    }
+    {   // level 4, size 128: u = (x3, x2x1x0): m = x3<<3 | (g3 ^ (x3?7:0))
+        const c64 w0 = tw(tw_idx(128, 2 * g3 + 1));
+        const c64 w1 = tw(tw_idx(128, 2 * (8 | (g3 ^ 7)) + 1));
+#pragma unroll
+        for (int g = 0; g < 8; g += 4) {
+            fwd_bf(v[g + 0], v[g + 2], w0);
+            fwd_bf(v[g + 1], v[g + 3], w1);
+        }
+    }
+    {   // level 5, size 256: u = (x4 x3, x2x1x0): m = igray2(x4x3)<<3 | (g3 ^ (parity?7:0))
+        const c64 w0 = tw(tw_idx(256, 2 * ((0 << 3) | g3) + 1));        // x4x3 = 00
+        const c64 w1 = tw(tw_idx(256, 2 * ((1 << 3) | (g3 ^ 7)) + 1));  // 01
+        const c64 w2 = tw(tw_idx(256, 2 * ((3 << 3) | (g3 ^ 7)) + 1));  // 10
+        const c64 w3 = tw(tw_idx(256, 2 * ((2 << 3) | g3) + 1));        // 11
+        fwd_bf(v[0], v[4], w0);
+        fwd_bf(v[1], v[5], w1);
+        fwd_bf(v[2], v[6], w2);
+        fwd_bf(v[3], v[7], w3);
+    }
+}
+
+template <class TW>
+BRC_HD void fwd_phaseC(c64 (&v)[8], int lane, const TW &tw) {
+    const int g6 = igray(lane);  // igray of x5..x0
+    {   // level 6, size 512
+        const c64 w = tw(tw_idx(512, 2 * g6 + 1));
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) fwd_bf(v[r], v[r + 1], w);
+    }
+    {   // level 7, size 1024
+        const c64 w0 = tw(tw_idx(1024, 2 * g6 + 1));
+        const c64 w1 = tw(tw_idx(1024, 2 * (64 | (g6 ^ 63)) + 1));
+#pragma unroll
+        for (int g = 0; g < 8; g += 4) {
+            fwd_bf(v[g + 0], v[g + 2], w0);
+            fwd_bf(v[g + 1], v[g + 3], w1);
+        }
+    }
+    {   // level 8, size 2048
+        const c64 w0 = tw(tw_idx(2048, 2 * ((0 << 6) | g6) + 1));
+        const c64 w1 = tw(tw_idx(2048, 2 * ((1 << 6) | (g6 ^ 63)) + 1));
+        const c64 w2 = tw(tw_idx(2048, 2 * ((3 << 6) | (g6 ^ 63)) + 1));
+        const c64 w3 = tw(tw_idx(2048, 2 * ((2 << 6) | g6) + 1));
+        fwd_bf(v[0], v[4], w0);
+        fwd_bf(v[1], v[5], w1);
+        fwd_bf(v[2], v[6], w2);
+        fwd_bf(v[3], v[7], w3);
+    }
+}
+
+// =================================================================================================================
+// INVERSE TRANSFORM, 1024 complex values, 16 per lane (reg rho = 4 bits).
+//   working index y (10 bits), W[y] initially c~[br10(y)].
+//   phase A: lane l, reg rho <-> y = br6(l)<<4 | rho                               (levels 0..3 on y0..y3)
+//   phase B: lane l, reg rho <-> y = (l>>3)<<7 | (rho>>1)<<4 | (rho&1)<<3 | (l&7)   (levels 4..6 on y4..y6 = rho bits 1..3)
+//   phase C: lane l, reg rho <-> y = (rho>>1)<<7 | (l>>3)<<4 | (rho&1)<<3 | (l&7)   (levels 7..9 on y7..y9 = rho bits 1..3)
+//   output: coefficient j = y of the polynomial.
+//   input of phase A: c~[m], m = br10(y) = br4(rho)<<6 | l
+// =================================================================================================================
+BRC_HD int inv_yA(int lane, int rho) { return (br6(lane) << 4) | rho; }
+BRC_HD int inv_yB(int lane, int rho) { return ((lane >> 3) << 7) | ((rho >> 1) << 4) | ((rho & 1) << 3) | (lane & 7); }
+BRC_HD int inv_yC(int lane, int rho) { return ((rho >> 1) << 7) | ((lane >> 3) << 4) | ((rho & 1) << 3) | (lane & 7); }
+
+template <class TW>
+BRC_HD void inv_phaseA(c64 (&v)[16], const TW &tw) {
+    // level 0 (size 2, polynomials.cpp:113-122): plain sum / difference
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const c64 a = v[r], b = v[r + 1];
+        v[r] = {a.re + b.re, a.im + b.im};
+        v[r + 1] = {a.re - b.re, a.im - b.im};
+    }
+    // level 1 (size 4, :125-145): even index plain, odd index twiddle -i
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) {
+        const c64 a = v[g], b = v[g + 2];
+        v[g] = {a.re + b.re, a.im + b.im};
+        v[g + 2] = {a.re - b.re, a.im - b.im};
+        const c64 c = v[g + 1], d = v[g + 3];
+        v[g + 1] = {c.re + d.im, c.im - d.re};
+        v[g + 3] = {c.re - d.im, c.im + d.re};
+    }
+    // level 2 (size 8): j = y & 3
+#pragma unroll
+    for (int g = 0; g < 16; g += 8) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) inv_bf(v[g + j], v[g + j + 4], tw(tw_idx(8, j)));
+    }
+    // level 3 (size 16): j = y & 7
+#pragma unroll
+    for (int j = 0; j < 8; j++) inv_bf(v[j], v[j + 8], tw(tw_idx(16, j)));
+}
+
+template <class TW>
+BRC_HD void inv_phaseB(c64 (&v)[16], int lane, const TW &tw) {
+    const int l3 = lane & 7;
+    // rho = (y6 y5 y4 | y3).  level 4 (size 32): pairs differ in y4 = rho bit1; j = y3<<3 | l3
+#pragma unroll
+    for (int y3 = 0; y3 < 2; y3++) {
+        const c64 w = tw(tw_idx(32, (y3 << 3) | l3));
+#pragma unroll
+        for (int hi = 0; hi < 4; hi++) {  // y6 y5
+            const int r0 = (hi << 2) | y3;
+            inv_bf(v[r0], v[r0 | 2], w);
+        }
+    }
+    // level 5 (size 64): pairs differ in y5 = rho bit2; j = y4<<4 | y3<<3 | l3
+#pragma unroll
+    for (int lo = 0; lo < 4; lo++) {  // y4 y3 = rho bits 1,0
+        const c64 w = tw(tw_idx(64, (lo << 3) | l3));
+#pragma unroll
+        for (int y6 = 0; y6 < 2; y6++) {
+            const int r0 = (y6 << 3) | lo;
+            inv_bf(v[r0], v[r0 | 4], w);
+        }
+    }
+    // level 6 (size 128): pairs differ in y6 = rho bit3; j = y5 y4 y3 l3
+#pragma unroll
+    for (int lo = 0; lo < 8; lo++) {
+        const c64 w = tw(tw_idx(128, (lo << 3) | l3));
+        inv_bf(v[lo], v[lo | 8], w);
+    }
+}
+
+template <class TW>
+BRC_HD void inv_phaseC(c64 (&v)[16], int lane, const TW &tw) {
+    // rho = (y9 y8 y7 | y3); lane = (y6 y5 y4 | y2 y1 y0); low 7 bits of y: lowj(y3) = (lane>>3)<<4 | y3<<3 | (lane&7)
+    const int base = ((lane >> 3) << 4) | (lane & 7);
+    // level 7 (size 256): pairs differ in y7 = rho bit1; j = y6..y0
+#pragma unroll
+    for (int y3 = 0; y3 < 2; y3++) {
+        const c64 w = tw(tw_idx(256, base | (y3 << 3)));
+#pragma unroll
+        for (int hi = 0; hi < 4; hi++) {
+            const int r0 = (hi << 2) | y3;
+            inv_bf(v[r0], v[r0 | 2], w);
+        }
+    }
+    // level 8 (size 512): pairs differ in y8 = rho bit2; j = y7<<7 | low7
+#pragma unroll
+    for (int lo = 0; lo < 4; lo++) {  // y7 y3
+        const c64 w = tw(tw_idx(512, ((lo >> 1) << 7) | base | ((lo & 1) << 3)));
+#pragma unroll
+        for (int y9 = 0; y9 < 2; y9++) {
+            const int r0 = (y9 << 3) | lo;
+            inv_bf(v[r0], v[r0 | 4], w);
+        }
+    }
+    // level 9 (size 1024): pairs differ in y9 = rho bit3; j = y8 y7<<7 | low7
+#pragma unroll
+    for (int lo = 0; lo < 8; lo++) {  // y8 y7 y3
+        const c64 w = tw(tw_idx(1024, ((lo >> 1) << 7) | base | ((lo & 1) << 3)));
+        inv_bf(v[lo], v[lo | 8], w);
+    }
+}
+
+// last merge (size 2048) + scaling + truncation: polynomials.cpp:160-166 with E = 0, then :392
+template <class TW>
+BRC_HD void inv_final(int32_t (&out)[16], const c64 (&v)[16], int lane, const TW &tw) {
+#pragma unroll
+    for (int rho = 0; rho < 16; rho++) {
+        const int y = inv_yC(lane, rho);
+        const c64 w = tw(tw_idx(2048, y));
+        const double tr = v[rho].re * w.re + v[rho].im * w.im;
+        const double scaled = tr * 4194304.0;  // (tr * 2^-10) * 2^32, both exact scalings
+        out[rho] = (int32_t) (uint32_t) (uint64_t) (int64_t) scaled;
+    }
+}
+
+// ---- integer pieces -------------------------------------------------------------------------------------------
+// ((X^a - 1) * acc)[j] for a in [0, 2N): reference toruspolynomial-functions.cpp:106-124, all cases folded into
+// one index computation: source index (j - a) mod 2N, negated when it falls in the upper half
+BRC_HD int32_t rot_minus_one(const int32_t *acc, int a, int j) {
+    const int s = (j - a) & (2 * kN - 1);
+    const uint32_t v = (uint32_t) acc[s & (kN - 1)];
+    const uint32_t rot = (s & kN) ? (0u - v) : v;
+    return (int32_t) (rot - (uint32_t) acc[j]);
+}
+// gadget digit p (0..l-1) of a Torus32: reference tgsw-functions.cpp:297-315
+BRC_HD int32_t decomp_digit(int32_t t, int p) {
+    const uint32_t u = (uint32_t) t + kDecompOffset;
+    return (int32_t) ((u >> (32 - (p + 1) * kBgbit)) & 127u) - 64;
+}
+// modSwitchFromTorus32(x, 2N): reference numeric-functions.cpp:59-65 (2^64/2N = 2^53 wide intervals)
+BRC_HD int32_t modswitch_2N(int32_t x) { return (int32_t) ((((uint32_t) x) + (1u << 20)) >> 21) & (2 * kN - 1); }
+
+}  // namespace brc

@@ -1,0 +1,990 @@
+// libtfhe_hip.so - HIP kernels (gfx950 / MI355X) and the C-ABI of include/tfhe_hip.h.
+//
+// Kernel inventory (reference functions each one replaces are cited at the kernel):
+//   k_blind_rotate<MODE>   one wavefront = one ciphertext through all n = 630 CMux iterations; the accumulator
+//                          lives in LDS, spectra live in registers, the FFT-domain bootstrapping key streams from
+//                          L2/HBM with 16-byte coalesced loads.  Fuses gate pre-combination, modulus switch,
+//                          test-vector rotation, blind rotation and sample extraction.
+//   k_keyswitch            batched gather-subtract over the keyswitch key, 32 gates per thread so each key row
+//                          fetched from L2 serves 32 ciphertexts.
+//   k_bk_convert / k_bk_permute / k_ks_pack     one-time key layout conversion on upload.
+//   k_poly_fwd / k_poly_inv / k_poly_mul        stage-level transforms (parity tests, FFT microbench).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the arithmetic contract of br_core.h forbids FMA
+// contraction).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "br_core.h"
+#include "../../include/tfhe_hip.h"
+
+#pragma clang fp contract(off)
+
+using namespace brc;
+
+namespace {
+
+constexpr int kExt = kN + 1;      // extracted LWE_N sample length
+constexpr int kCt = kLwe + 1;     // LWE_n sample length
+constexpr int kKsRow = 632;       // keyswitch row padded to a multiple of 4 dwords
+constexpr int kKsT = 8, kKsBasebit = 2;
+
+// ---------------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------------
+struct TwUniform {  // compile-time / wave-uniform indices: read through the scalar cache from global memory
+    const c64 *t;
+    __device__ __forceinline__ c64 operator()(int i) const { return t[i]; }
+};
+struct TwLds {  // lane-dependent indices: read from the LDS copy of the table
+    const c64 *t;
+    __device__ __forceinline__ c64 operator()(int i) const { return t[i]; }
+};
+
+// Exchanges between lanes of ONE wave go through LDS without a workgroup barrier: LDS operations of a wave are
+// executed in issue order, so only the compiler has to be kept from reordering them.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void wave_fwd(c64 (&v)[8], int lane, c64 *scratch, const TwUniform &twu, const TwLds &twl) {
+    fwd_phaseA(v, twu);
+#pragma unroll
+    for (int r = 0; r < 8; r++) scratch[swz(fwd_xA(lane, r))] = v[r];
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xB(lane, r))];
+    wave_sync();
+    fwd_phaseB(v, lane, twl);
+#pragma unroll
+    for (int r = 0; r < 8; r++) scratch[swz(fwd_xB(lane, r))] = v[r];
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xC(lane, r))];
+    wave_sync();
+    fwd_phaseC(v, lane, twl);
+}
+
+// element index inside one half (fixed y3) of the 1024-entry inverse working array
+__device__ __forceinline__ int inv_elem(int y) { return ((y >> 4) << 3) | (y & 7); }
+
+__device__ __forceinline__ void wave_inv(int32_t (&out)[16], c64 (&v)[16], int lane, c64 *scratch,
+                                         const TwUniform &twu, const TwLds &twl) {
+    inv_phaseA(v, twu);
+    c64 w[16];
+    // layout A (regs y3y2y1y0) -> layout B (regs y6y5y4,y3), one half (y3) at a time through the 8 KB scratch
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) scratch[swz(inv_elem(inv_yA(lane, (h << 3) | q)))] = v[(h << 3) | q];
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 8; q++) w[(q << 1) | h] = scratch[swz(inv_elem(inv_yB(lane, (q << 1) | h)))];
+        wave_sync();
+    }
+    inv_phaseB(w, lane, twl);
+    // layout B -> layout C (regs y9y8y7,y3)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) scratch[swz(inv_elem(inv_yB(lane, (q << 1) | h)))] = w[(q << 1) | h];
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[(q << 1) | h] = scratch[swz(inv_elem(inv_yC(lane, (q << 1) | h)))];
+        wave_sync();
+    }
+    inv_phaseC(v, lane, twl);
+    inv_final(out, v, lane, twl);
+}
+
+// spectrum held as (lane, r) <-> physical slot x = r<<6|lane  ->  inverse-transform input registers, via scratch
+__device__ __forceinline__ void spectrum_to_inv_input(c64 (&v)[16], const c64 (&s)[8], int lane, c64 *scratch) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) scratch[swz(fwd_xC(lane, r))] = s[r];
+    wave_sync();
+#pragma unroll
+    for (int rho = 0; rho < 16; rho++) {
+        const int m = (br4(rho) << 6) | lane;
+        if (br4(rho) < 8) {
+            v[rho] = scratch[swz(gray(m))];
+        } else {
+            const c64 t = scratch[swz(gray(1023 - m))];
+            v[rho] = {t.re, -t.im};
+        }
+    }
+    wave_sync();
+}
+
+// complex product as the reference's std::complex<double> operator* evaluates it (polynomials.cpp:313-323)
+__device__ __forceinline__ void cmac(c64 &acc, const c64 a, const c64 b) {
+    const double ac = a.re * b.re, bd = a.im * b.im, ad = a.re * b.im, bc = a.im * b.re;
+    acc.re += ac - bd;
+    acc.im += ad + bc;
+}
+
+__device__ __forceinline__ void load_tw_to_lds(c64 *tw_lds, const c64 *tw) {
+    for (int i = threadIdx.x; i < kTwEntries; i += blockDim.x) tw_lds[i] = tw[i];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// blind rotation
+// ---------------------------------------------------------------------------------------------------------------
+struct BrArgs {
+    const int32_t *a, *b;  // MODE_GATE: LWE_n inputs [B][n+1] (b may be null)
+    int32_t sa, sb, cst;   //            tmp = (0,cst) + sa*a + sb*b          (boot-gates.cpp)
+    int32_t mu;            //            test vector constant
+    int32_t *out;          // MODE_GATE: extracted LWE_N samples [B][N+1]
+    int32_t *acc_io;       // MODE_RAW / MODE_EXTMUL: TLWE accumulators [B][2][N], in/out
+    const int32_t *bara;   // MODE_RAW: [B][n] rotation amounts; MODE_EXTMUL: [B] key index
+    const c64 *bk;         // [n][6][2][8][64] physical slot order
+    const c64 *tw;         // twiddle table, kTwEntries
+    long long B;
+};
+enum { MODE_GATE = 0, MODE_RAW = 1, MODE_EXTMUL = 2 };
+
+constexpr int kBrLdsPerWave = 2 * kN * 4 + kNh * 16;  // accumulator + scratch = 16 KB
+
+// One CMux:  ACC <- ACC + bk_i (*) ((X^bara - 1) ACC)
+//   reference tfhe_MuxRotate_FFT (lwe-bootstrapping-functions-fft.cpp:68-77)
+//     = tLweMulByXaiMinusOne (tlwe-functions.cpp:202)  ->  tGswFFTExternMulToTLwe (tgsw-fft-operations.cpp:92-120)
+//       -> tLweAddTo (tlwe-functions.cpp:149)
+// EXTMUL variant: ACC <- bk_i (*) ACC (the external product alone).
+template <bool ROTATE>
+__device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int bara, const c64 *bki,
+                                     const TwUniform &twu, const TwLds &twl) {
+    c64 tmpa[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) tmpa[c][r] = {0.0, 0.0};
+
+#pragma unroll 1
+    for (int c = 0; c < 2; c++) {
+        int32_t tlo[8], thi[8];
+        const int32_t *accc = acc + c * kN;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int j = (br3(r) << 6) | lane;
+            if (ROTATE) {
+                tlo[r] = rot_minus_one(accc, bara, j);
+                thi[r] = rot_minus_one(accc, bara, j + kNh);
+            } else {
+                tlo[r] = accc[j];
+                thi[r] = accc[j + kNh];
+            }
+        }
+#pragma unroll 1
+        for (int p = 0; p < kL; p++) {
+            c64 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                v[r] = {(double) decomp_digit(tlo[r], p), (double) decomp_digit(thi[r], p)};
+            wave_fwd(v, lane, scratch, twu, twl);
+            const c64 *row = bki + (size_t) ((c * kL + p) * 2) * kNh + lane;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) cmac(tmpa[c2][r], v[r], row[c2 * kNh + r * 64]);
+        }
+    }
+#pragma unroll 1
+    for (int c2 = 0; c2 < 2; c2++) {
+        c64 v[16];
+        int32_t res[16];
+        if (c2 == 0) spectrum_to_inv_input(v, tmpa[0], lane, scratch);
+        else spectrum_to_inv_input(v, tmpa[1], lane, scratch);
+        wave_inv(res, v, lane, scratch, twu, twl);
+        int32_t *accc = acc + c2 * kN;
+#pragma unroll
+        for (int rho = 0; rho < 16; rho++) {
+            const int y = inv_yC(lane, rho);
+            accc[y] = ROTATE ? (int32_t) ((uint32_t) accc[y] + (uint32_t) res[rho]) : res[rho];
+        }
+    }
+    wave_sync();
+}
+
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
+    load_tw_to_lds(tw_lds, A.tw);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    unsigned char *mine = lds_raw + kTwEntries * sizeof(c64) + (size_t) wave * kBrLdsPerWave;
+    int32_t *acc = reinterpret_cast<int32_t *>(mine);
+    c64 *scratch = reinterpret_cast<c64 *>(mine + 2 * kN * 4);
+    const long long g = (long long) blockIdx.x * WAVES + wave;
+    if (g >= A.B) return;  // wave-uniform; no workgroup barrier after this point
+    const TwUniform twu{A.tw};
+    const TwLds twl{tw_lds};
+
+    if (MODE == MODE_GATE) {
+        // tfhe_bootstrap_woKS_FFT (lwe-bootstrapping-functions-fft.cpp:222-253) with the gate's linear
+        // pre-combination folded in; tfhe_blindRotateAndExtract_FFT (:180-209)
+        const int32_t *ga = A.a + g * kCt;
+        const int32_t *gb = A.b ? A.b + g * kCt : nullptr;
+        auto comb = [&](int i) -> int32_t {
+            uint32_t t = (uint32_t) A.sa * (uint32_t) ga[i];
+            if (gb) t += (uint32_t) A.sb * (uint32_t) gb[i];
+            return (int32_t) t;
+        };
+        const int barb = modswitch_2N((int32_t) ((uint32_t) comb(kLwe) + (uint32_t) A.cst));
+        // ACC = (0, X^(2N-barb) * [mu,...,mu])   (torusPolynomialMulByXai, toruspolynomial-functions.cpp:128-147)
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int j = q * 64 + lane;
+            acc[j] = 0;
+            acc[kN + j] = ((j + barb) & kN) ? (int32_t) (0u - (uint32_t) A.mu) : A.mu;
+        }
+        wave_sync();
+#pragma unroll 1
+        for (int i = 0; i < kLwe; i++) {
+            const int bara = __builtin_amdgcn_readfirstlane(modswitch_2N(comb(i)));
+            if (bara == 0) continue;  // lwe-bootstrapping-functions-fft.cpp:154
+            cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+        }
+        // tLweExtractLweSampleIndex(index 0), lwe.cpp:41-53
+        int32_t *o = A.out + g * kExt;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int j = q * 64 + lane;
+            o[j] = j == 0 ? acc[0] : (int32_t) (0u - (uint32_t) acc[kN - j]);
+        }
+        if (lane == 0) o[kN] = acc[kN];
+    } else {
+        int32_t *io = A.acc_io + g * 2 * kN;
+#pragma unroll
+        for (int q = 0; q < 32; q++) acc[q * 64 + lane] = io[q * 64 + lane];
+        wave_sync();
+        if (MODE == MODE_RAW) {
+            // tfhe_blindRotate_FFT (the reference's device seam), CPU loop at :146-164
+            const int32_t *gbara = A.bara + g * kLwe;
+#pragma unroll 1
+            for (int i = 0; i < kLwe; i++) {
+                const int bara = __builtin_amdgcn_readfirstlane(gbara[i]) & (2 * kN - 1);
+                if (bara == 0) continue;
+                cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+            }
+        } else {
+            const int i = __builtin_amdgcn_readfirstlane(A.bara[g]);
+            cmux<false>(acc, scratch, lane, 0, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+        }
+#pragma unroll
+        for (int q = 0; q < 32; q++) io[q * 64 + lane] = acc[q * 64 + lane];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// keyswitch: lweKeySwitch (lwe-keyswitch-functions.cpp:228-238) + lweKeySwitchTranslate_fromArray (:114-129)
+//   out = (0, b') - sum_{i<N, j<t} ks[i][j][digit_ij],  digit_ij = ((a'_i + 2^15) >> (30 - 2j)) & 3, digit 0 skipped
+// grid (ceil(B/G), 3), block 256: thread = one output coefficient q, G ciphertexts in registers.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kKsG = 32;
+__global__ __launch_bounds__(256) void k_keyswitch(const int32_t *__restrict__ in, const int32_t *__restrict__ ks,
+                                                   int32_t *__restrict__ out, long long B) {
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    const bool active = q <= kLwe;
+    const int qq = active ? q : kLwe;
+    const long long g0 = (long long) blockIdx.x * kKsG;
+    uint32_t acc[kKsG];
+#pragma unroll
+    for (int g = 0; g < kKsG; g++) {
+        const long long gi = (g0 + g < B) ? g0 + g : B - 1;
+        acc[g] = (qq == kLwe) ? (uint32_t) in[gi * kExt + kN] : 0u;
+    }
+    const uint32_t prec_offset = 1u << (32 - (1 + kKsBasebit * kKsT));
+#pragma unroll 1
+    for (int i = 0; i < kN; i++) {
+        uint32_t abar[kKsG];
+#pragma unroll
+        for (int g = 0; g < kKsG; g++) {
+            const long long gi = (g0 + g < B) ? g0 + g : B - 1;
+            abar[g] = (uint32_t) in[gi * kExt + i] + prec_offset;
+        }
+        const int32_t *rows = ks + (size_t) i * kKsT * 3 * kKsRow + qq;
+#pragma unroll
+        for (int j = 0; j < kKsT; j++) {
+            const uint32_t r1 = (uint32_t) rows[(j * 3 + 0) * kKsRow];
+            const uint32_t r2 = (uint32_t) rows[(j * 3 + 1) * kKsRow];
+            const uint32_t r3 = (uint32_t) rows[(j * 3 + 2) * kKsRow];
+#pragma unroll
+            for (int g = 0; g < kKsG; g++) {
+                const uint32_t d = (abar[g] >> (30 - 2 * j)) & 3u;
+                const uint32_t sel = d == 1 ? r1 : (d == 2 ? r2 : (d == 3 ? r3 : 0u));
+                acc[g] -= sel;
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int g = 0; g < kKsG; g++)
+            if (g0 + g < B) out[(g0 + g) * kCt + q] = (int32_t) acc[g];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small element-wise kernels of the gate layer
+// ---------------------------------------------------------------------------------------------------------------
+// bootsMUX tail (boot-gates.cpp:357-361): u1 <- (0,MU) + u1 + u2 on LWE_N samples
+__global__ void k_mux_combine(int32_t *u1, const int32_t *u2, int32_t mu, long long total) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    uint32_t v = (uint32_t) u1[i] + (uint32_t) u2[i];
+    if (i % kExt == kN) v += (uint32_t) mu;
+    u1[i] = (int32_t) v;
+}
+// bootsNOT / bootsCOPY / bootsCONSTANT (boot-gates.cpp:164-189)
+__global__ void k_linear_gate(int32_t *out, const int32_t *a, int gate, int32_t mu, long long total) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int32_t v;
+    if (gate == TFHE_HIP_NOT) v = (int32_t) (0u - (uint32_t) a[i]);
+    else if (gate == TFHE_HIP_COPY) v = a[i];
+    else v = (i % kCt == kLwe) ? (gate == TFHE_HIP_CONST1 ? mu : (int32_t) (0u - (uint32_t) mu)) : 0;
+    out[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// key conversion
+// ---------------------------------------------------------------------------------------------------------------
+// tGswToFFTConvert (tgsw-fft-operations.cpp:52-57) = TorusPolynomial_ifft (polynomials.cpp:364-376) on each of
+// the n*6*2 polynomials; result stored in physical slot order [poly][r][lane]
+__global__ __launch_bounds__(256) void k_bk_convert(const int32_t *__restrict__ coef, c64 *__restrict__ bk,
+                                                    const c64 *__restrict__ tw, int npoly) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
+    load_tw_to_lds(tw_lds, tw);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwEntries * sizeof(c64)) + wave * kNh;
+    const int poly = blockIdx.x * 4 + wave;
+    if (poly >= npoly) return;
+    const int32_t *p = coef + (size_t) poly * kN;
+    c64 v[8];
+    const double s = 1.0 / 4294967296.0;  // 2 * 2^-33: the size-2 merge doubles the reference's 2^-33 scaling exactly
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int j = (br3(r) << 6) | lane;
+        v[r] = {p[j] * s, p[j + kNh] * s};
+    }
+    wave_fwd(v, lane, scratch, TwUniform{tw}, TwLds{tw_lds});
+#pragma unroll
+    for (int r = 0; r < 8; r++) bk[(size_t) poly * kNh + r * 64 + lane] = v[r];
+}
+// reference (logical LagrangeHalfC) order <-> physical slot order: slot x holds bin igray(x)
+__global__ void k_bk_permute(c64 *dst, const c64 *src, long long total, int to_physical) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long poly = i >> 9;
+    const int x = (int) (i & 511);
+    if (to_physical) dst[i] = src[poly * kNh + igray(x)];
+    else dst[poly * kNh + igray(x)] = src[i];
+}
+// [N][t][4][n+1] -> [N][t][3][632] (digit 0 rows are never read: lwe-keyswitch-functions.cpp:126)
+__global__ void k_ks_pack(int32_t *dst, const int32_t *src, long long rows) {
+    const long long row = blockIdx.x;
+    if (row >= rows) return;
+    const long long ij = row / 3;
+    const int d = (int) (row % 3) + 1;
+    const int32_t *s = src + (ij * 4 + d) * kCt;
+    int32_t *o = dst + row * kKsRow;
+    for (int q = threadIdx.x; q < kKsRow; q += blockDim.x) o[q] = q < kCt ? s[q] : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stage-level transforms (one wave per polynomial, 4 waves per block)
+// ---------------------------------------------------------------------------------------------------------------
+// IntPolynomial_ifft (polynomials.cpp:347) / TorusPolynomial_ifft (:364); spectra written in the reference order
+__global__ __launch_bounds__(256) void k_poly_fwd(const int32_t *__restrict__ polys, c64 *__restrict__ spectra,
+                                                  const c64 *__restrict__ tw, long long count, int torus) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
+    load_tw_to_lds(tw_lds, tw);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwEntries * sizeof(c64)) + wave * kNh;
+    const long long poly = (long long) blockIdx.x * 4 + wave;
+    if (poly >= count) return;
+    const int32_t *p = polys + poly * kN;
+    const double s = torus ? 1.0 / 4294967296.0 : 1.0;
+    c64 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int j = (br3(r) << 6) | lane;
+        v[r] = {p[j] * s, p[j + kNh] * s};
+    }
+    wave_fwd(v, lane, scratch, TwUniform{tw}, TwLds{tw_lds});
+#pragma unroll
+    for (int r = 0; r < 8; r++) spectra[poly * kNh + igray(fwd_xC(lane, r))] = v[r];
+}
+// TorusPolynomial_fft (polynomials.cpp:378-393); spectra read in the reference order
+__global__ __launch_bounds__(256) void k_poly_inv(const c64 *__restrict__ spectra, int32_t *__restrict__ polys,
+                                                  const c64 *__restrict__ tw, long long count) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
+    load_tw_to_lds(tw_lds, tw);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwEntries * sizeof(c64)) + wave * kNh;
+    const long long poly = (long long) blockIdx.x * 4 + wave;
+    if (poly >= count) return;
+    const c64 *C = spectra + poly * kNh;
+    c64 v[16];
+#pragma unroll
+    for (int rho = 0; rho < 16; rho++) {
+        const int m = (br4(rho) << 6) | lane;
+        if (br4(rho) < 8) v[rho] = C[m];
+        else {
+            const c64 t = C[1023 - m];
+            v[rho] = {t.re, -t.im};
+        }
+    }
+    int32_t res[16];
+    wave_inv(res, v, lane, scratch, TwUniform{tw}, TwLds{tw_lds});
+#pragma unroll
+    for (int rho = 0; rho < 16; rho++) polys[poly * kN + inv_yC(lane, rho)] = res[rho];
+}
+// torusPolynomialMultFFT (polynomials.cpp:241-248): out = ipoly * tpoly
+__global__ __launch_bounds__(256) void k_poly_mul(const int32_t *__restrict__ ipolys, const int32_t *__restrict__ tpolys,
+                                                  int32_t *__restrict__ out, const c64 *__restrict__ tw,
+                                                  long long count) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
+    load_tw_to_lds(tw_lds, tw);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwEntries * sizeof(c64)) + wave * kNh;
+    const long long poly = (long long) blockIdx.x * 4 + wave;
+    if (poly >= count) return;
+    const TwUniform twu{tw};
+    const TwLds twl{tw_lds};
+    c64 a[8], b[8], prod[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int j = (br3(r) << 6) | lane;
+        a[r] = {(double) ipolys[poly * kN + j], (double) ipolys[poly * kN + j + kNh]};
+        b[r] = {tpolys[poly * kN + j] * (1.0 / 4294967296.0), tpolys[poly * kN + j + kNh] * (1.0 / 4294967296.0)};
+    }
+    wave_fwd(a, lane, scratch, twu, twl);
+    wave_fwd(b, lane, scratch, twu, twl);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {  // LagrangeHalfCPolynomialMul, polynomials.cpp:301-310
+        const double ac = a[r].re * b[r].re, bd = a[r].im * b[r].im, ad = a[r].re * b[r].im, bc = a[r].im * b[r].re;
+        prod[r] = {ac - bd, ad + bc};
+    }
+    c64 v[16];
+    int32_t res[16];
+    spectrum_to_inv_input(v, prod, lane, scratch);
+    wave_inv(res, v, lane, scratch, twu, twl);
+#pragma unroll
+    for (int rho = 0; rho < 16; rho++) out[poly * kN + inv_yC(lane, rho)] = res[rho];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(x)                                                                                          \
+    do {                                                                                                   \
+        hipError_t e_ = (x);                                                                               \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(TFHE_HIP_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+// Twiddle tables.  The reference hard-codes them (src/include/tfhe_core.h:26,93); they equal double-precision
+// libm cos/sin of the angle folded into the first octant.  Regenerated here and checked against a fingerprint of
+// the reference values, so that a host libm that rounds differently is detected instead of silently changing bits.
+double oct_cos(int j, int n) {
+    const double w = 2.0 * M_PI;
+    if (4 * j == n) return 0.0;
+    if (8 * j <= n) return cos(w * j / n);
+    if (4 * j <= n) return sin(w * (n / 4 - j) / n);
+    if (8 * j < 3 * n) return -sin(w * (j - n / 4) / n);
+    return -cos(w * (n / 2 - j) / n);
+}
+double oct_sin(int j, int n) {
+    const double w = 2.0 * M_PI;
+    if (8 * j < n) return sin(w * j / n);
+    if (4 * j <= n) return cos(w * (n / 4 - j) / n);
+    if (8 * j <= 3 * n) return cos(w * (j - n / 4) / n);
+    return sin(w * (n / 2 - j) / n);
+}
+constexpr uint64_t kTwFingerprint = 0x749e3b06997a84d7ULL;
+bool build_twiddles(std::vector<c64> &tw) {
+    tw.resize(kTwEntries);
+    uint64_t h = 1469598103934665603ULL;
+    auto mix = [&](double v) {
+        uint64_t u;
+        if (v == 0.0) v = 0.0;
+        memcpy(&u, &v, 8);
+        for (int b = 0; b < 8; b++) {
+            h ^= (u >> (8 * b)) & 0xff;
+            h *= 1099511628211ULL;
+        }
+    };
+    for (int size = 8; size <= 2048; size *= 2) {
+        for (int j = 0; j < size / 2; j++) tw[tw_idx(size, j)] = {oct_cos(j, size), oct_sin(j, size)};
+        for (int j = 0; j < size / 2; j++) mix(tw[tw_idx(size, j)].re);
+        for (int j = 0; j < size / 2; j++) mix(tw[tw_idx(size, j)].im);
+    }
+    return h == kTwFingerprint;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct tfhe_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    c64 *tw = nullptr;
+    c64 *bk = nullptr;       // [n][6][2][512] physical order
+    int32_t *ks = nullptr;   // [N][t][3][632]
+    bool have_keys = false;
+    DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // br start/stop, ks start/stop
+    bool ev_br = false, ev_ks = false;
+    int br_waves = 4;
+};
+
+namespace {
+
+constexpr size_t kBkBytes = (size_t) kLwe * kKpl * 2 * kNh * sizeof(c64);
+constexpr size_t kKsDevBytes = (size_t) kN * kKsT * 3 * kKsRow * sizeof(int32_t);
+constexpr size_t kKsHostElems = (size_t) kN * kKsT * 4 * kCt;
+constexpr int kFftLds = kTwEntries * (int) sizeof(c64) + 4 * kNh * (int) sizeof(c64);
+
+template <int MODE>
+int launch_br(tfhe_hip_ctx *c, const BrArgs &A) {
+    if (A.B <= 0) return TFHE_HIP_OK;
+    const int waves = c->br_waves;
+    const size_t lds = kTwEntries * sizeof(c64) + (size_t) waves * kBrLdsPerWave;
+    const unsigned grid = (unsigned) ((A.B + waves - 1) / waves);
+    if (waves == 8) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate<MODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int) lds));
+        hipLaunchKernelGGL((k_blind_rotate<MODE, 8>), dim3(grid), dim3(512), lds, c->stream, A);
+    } else {
+        HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate<MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int) lds));
+        hipLaunchKernelGGL((k_blind_rotate<MODE, 4>), dim3(grid), dim3(256), lds, c->stream, A);
+    }
+    HIPCHK(hipGetLastError());
+    return TFHE_HIP_OK;
+}
+
+int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B) {
+    if (B <= 0) return TFHE_HIP_OK;
+    dim3 grid((unsigned) ((B + kKsG - 1) / kKsG), 3);
+    hipLaunchKernelGGL(k_keyswitch, grid, dim3(256), 0, c->stream, d_in, c->ks, d_out, B);
+    HIPCHK(hipGetLastError());
+    return TFHE_HIP_OK;
+}
+
+struct GateLin {
+    int32_t cst, sa, sb;
+};
+// constants of boot-gates.cpp; modSwitchToTorus32(+-1,8) = +-2^29, (+-1,4) = +-2^30 (numeric-functions.cpp:71-76)
+const int32_t kMU = 1 << 29;
+bool gate_lin(int gate, GateLin &g) {
+    switch (gate) {
+        case TFHE_HIP_NAND: g = {kMU, -1, -1}; return true;
+        case TFHE_HIP_OR: g = {kMU, 1, 1}; return true;
+        case TFHE_HIP_AND: g = {-kMU, 1, 1}; return true;
+        case TFHE_HIP_XOR: g = {2 * kMU, 2, 2}; return true;
+        case TFHE_HIP_XNOR: g = {-2 * kMU, -2, -2}; return true;
+        case TFHE_HIP_NOR: g = {-kMU, -1, -1}; return true;
+        case TFHE_HIP_ANDNY: g = {-kMU, -1, 1}; return true;
+        case TFHE_HIP_ANDYN: g = {-kMU, 1, -1}; return true;
+        case TFHE_HIP_ORNY: g = {kMU, -1, 1}; return true;
+        case TFHE_HIP_ORYN: g = {kMU, 1, -1}; return true;
+        default: return false;
+    }
+}
+
+int check_ctx(tfhe_hip_ctx *c, bool need_keys) {
+    if (!c) return fail(TFHE_HIP_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    if (need_keys && !c->have_keys) return fail(TFHE_HIP_ERR_NOKEY, "keys not loaded");
+    return TFHE_HIP_OK;
+}
+
+int upload_ks(tfhe_hip_ctx *c, const int32_t *ks) {
+    HIPCHK(c->misc.reserve(kKsHostElems * sizeof(int32_t)));
+    HIPCHK(hipMemcpyAsync(c->misc.p, ks, kKsHostElems * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (!c->ks) HIPCHK(hipMalloc((void **) &c->ks, kKsDevBytes));
+    const long long rows = (long long) kN * kKsT * 3;
+    hipLaunchKernelGGL(k_ks_pack, dim3((unsigned) rows), dim3(256), 0, c->stream, c->ks, (const int32_t *) c->misc.p, rows);
+    HIPCHK(hipGetLastError());
+    return TFHE_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *tfhe_hip_last_error(void) { return g_err.c_str(); }
+
+int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
+    if (!out) return fail(TFHE_HIP_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(TFHE_HIP_ERR_ARG, "no such device");
+    std::vector<c64> tw;
+    if (!build_twiddles(tw))
+        return fail(TFHE_HIP_ERR_TABLE, "twiddle table fingerprint mismatch: host libm cos/sin round differently");
+    HIPCHK(hipSetDevice(device));
+    tfhe_hip_ctx *c = new tfhe_hip_ctx();
+    c->device = device;
+    const char *w = getenv("TFHE_HIP_BR_WAVES");
+    if (w && atoi(w) == 8) c->br_waves = 8;
+    if (w && atoi(w) == 4) c->br_waves = 4;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **) &c->tw, kTwEntries * sizeof(c64));
+    if (e == hipSuccess) e = hipMemcpy(c->tw, tw.data(), kTwEntries * sizeof(c64), hipMemcpyHostToDevice);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+        tfhe_hip_destroy(c);
+        return fail(TFHE_HIP_ERR_HIP, std::string("context creation: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return TFHE_HIP_OK;
+}
+
+void tfhe_hip_destroy(tfhe_hip_ctx *c) {
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->in_a, &c->in_b, &c->in_c, &c->ext1, &c->ext2, &c->outb, &c->misc}) b->release();
+    if (c->tw) (void) hipFree(c->tw);
+    if (c->bk) (void) hipFree(c->bk);
+    if (c->ks) (void) hipFree(c->ks);
+    for (int i = 0; i < 4; i++)
+        if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void *tfhe_hip_stream(tfhe_hip_ctx *c) { return c ? (void *) c->stream : nullptr; }
+
+int tfhe_hip_sync(tfhe_hip_ctx *c) {
+    if (int r = check_ctx(c, false)) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TFHE_HIP_OK;
+}
+
+int tfhe_hip_load_keys_coef(tfhe_hip_ctx *c, const int32_t *bk_coef, const int32_t *ks) {
+    if (int r = check_ctx(c, false)) return r;
+    if (!bk_coef || !ks) return fail(TFHE_HIP_ERR_ARG, "null key pointer");
+    c->have_keys = false;
+    const int npoly = kLwe * kKpl * 2;
+    const size_t coef_bytes = (size_t) npoly * kN * sizeof(int32_t);
+    if (!c->bk) HIPCHK(hipMalloc((void **) &c->bk, kBkBytes));
+    HIPCHK(c->misc.reserve(coef_bytes));
+    HIPCHK(hipMemcpyAsync(c->misc.p, bk_coef, coef_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipFuncSetAttribute((const void *) k_bk_convert, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
+    hipLaunchKernelGGL(k_bk_convert, dim3((npoly + 3) / 4), dim3(256), kFftLds, c->stream, (const int32_t *) c->misc.p,
+                       c->bk, (const c64 *) c->tw, npoly);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));  // misc is reused by upload_ks
+    if (int r = upload_ks(c, ks)) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->misc.release();
+    c->have_keys = true;
+    return TFHE_HIP_OK;
+}
+
+int tfhe_hip_load_keys_fft(tfhe_hip_ctx *c, const double *bkfft, const int32_t *ks) {
+    if (int r = check_ctx(c, false)) return r;
+    if (!bkfft || !ks) return fail(TFHE_HIP_ERR_ARG, "null key pointer");
+    c->have_keys = false;
+    if (!c->bk) HIPCHK(hipMalloc((void **) &c->bk, kBkBytes));
+    HIPCHK(c->misc.reserve(kBkBytes));
+    HIPCHK(hipMemcpyAsync(c->misc.p, bkfft, kBkBytes, hipMemcpyHostToDevice, c->stream));
+    const long long total = (long long) kLwe * kKpl * 2 * kNh;
+    hipLaunchKernelGGL(k_bk_permute, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream, c->bk,
+                       (const c64 *) c->misc.p, total, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (int r = upload_ks(c, ks)) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->misc.release();
+    c->have_keys = true;
+    return TFHE_HIP_OK;
+}
+
+int tfhe_hip_get_bkfft(tfhe_hip_ctx *c, double *out) {
+    if (int r = check_ctx(c, true)) return r;
+    if (!out) return fail(TFHE_HIP_ERR_ARG, "null output");
+    HIPCHK(c->misc.reserve(kBkBytes));
+    const long long total = (long long) kLwe * kKpl * 2 * kNh;
+    hipLaunchKernelGGL(k_bk_permute, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream, (c64 *) c->misc.p,
+                       (const c64 *) c->bk, total, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->misc.p, kBkBytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->misc.release();
+    return TFHE_HIP_OK;
+}
+
+// ---- device-resident entry points -----------------------------------------------------------------------------
+int tfhe_hip_bootstrap_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, int32_t mu, int64_t count,
+                                 int with_ks) {
+    if (int r = check_ctx(c, true)) return r;
+    if (count < 0 || (count > 0 && (!d_out || !d_in))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    c->ev_br = c->ev_ks = false;
+    if (count == 0) return TFHE_HIP_OK;
+    int32_t *ext = d_out;
+    if (with_ks) {
+        HIPCHK(c->ext1.reserve((size_t) count * kExt * sizeof(int32_t)));
+        ext = (int32_t *) c->ext1.p;
+    }
+    BrArgs A{};
+    A.a = d_in; A.b = nullptr; A.sa = 1; A.sb = 0; A.cst = 0; A.mu = mu; A.out = ext;
+    A.bk = c->bk; A.tw = c->tw; A.B = count;
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    if (int r = launch_br<MODE_GATE>(c, A)) return r;
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    c->ev_br = true;
+    if (with_ks) {
+        HIPCHK(hipEventRecord(c->ev[2], c->stream));
+        if (int r = launch_ks(c, d_out, ext, count)) return r;
+        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        c->ev_ks = true;
+    }
+    return TFHE_HIP_OK;
+}
+
+int tfhe_hip_keyswitch_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, int64_t count) {
+    if (int r = check_ctx(c, true)) return r;
+    if (count < 0 || (count > 0 && (!d_out || !d_in))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    c->ev_br = c->ev_ks = false;
+    if (count == 0) return TFHE_HIP_OK;
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    if (int r = launch_ks(c, d_out, d_in, count)) return r;
+    HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    c->ev_ks = true;
+    return TFHE_HIP_OK;
+}
+
+int tfhe_hip_gate_batch_dev(tfhe_hip_ctx *c, int gate, int32_t *d_out, const int32_t *d_a, const int32_t *d_b,
+                            const int32_t *d_c, int64_t count) {
+    if (int r = check_ctx(c, gate <= TFHE_HIP_MUX)) return r;
+    if (gate < TFHE_HIP_NAND || gate > TFHE_HIP_CONST0) return fail(TFHE_HIP_ERR_ARG, "unknown gate id");
+    if (count < 0 || (count > 0 && !d_out)) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    c->ev_br = c->ev_ks = false;
+    if (count == 0) return TFHE_HIP_OK;
+    const bool unary = gate == TFHE_HIP_NOT || gate == TFHE_HIP_COPY;
+    const bool nullary = gate == TFHE_HIP_CONST0 || gate == TFHE_HIP_CONST1;
+    if (!nullary && !d_a) return fail(TFHE_HIP_ERR_ARG, "null input a");
+    if (!nullary && !unary && !d_b) return fail(TFHE_HIP_ERR_ARG, "null input b");
+    if (gate == TFHE_HIP_MUX && !d_c) return fail(TFHE_HIP_ERR_ARG, "null input c");
+    if (unary || nullary) {
+        const long long total = (long long) count * kCt;
+        hipLaunchKernelGGL(k_linear_gate, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream, d_out, d_a,
+                           gate, kMU, total);
+        HIPCHK(hipGetLastError());
+        return TFHE_HIP_OK;
+    }
+    HIPCHK(c->ext1.reserve((size_t) count * kExt * sizeof(int32_t)));
+    BrArgs A{};
+    A.mu = kMU; A.bk = c->bk; A.tw = c->tw; A.B = count;
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    if (gate == TFHE_HIP_MUX) {  // boot-gates.cpp:329-370
+        HIPCHK(c->ext2.reserve((size_t) count * kExt * sizeof(int32_t)));
+        A.a = d_a; A.b = d_b; A.sa = 1; A.sb = 1; A.cst = -kMU; A.out = (int32_t *) c->ext1.p;
+        if (int r = launch_br<MODE_GATE>(c, A)) return r;
+        A.a = d_a; A.b = d_c; A.sa = -1; A.sb = 1; A.cst = -kMU; A.out = (int32_t *) c->ext2.p;
+        if (int r = launch_br<MODE_GATE>(c, A)) return r;
+        const long long total = (long long) count * kExt;
+        hipLaunchKernelGGL(k_mux_combine, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream,
+                           (int32_t *) c->ext1.p, (const int32_t *) c->ext2.p, kMU, total);
+        HIPCHK(hipGetLastError());
+    } else {
+        GateLin g;
+        gate_lin(gate, g);
+        A.a = d_a; A.b = d_b; A.sa = g.sa; A.sb = g.sb; A.cst = g.cst; A.out = (int32_t *) c->ext1.p;
+        if (int r = launch_br<MODE_GATE>(c, A)) return r;
+    }
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    c->ev_br = true;
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    if (int r = launch_ks(c, d_out, (const int32_t *) c->ext1.p, count)) return r;
+    HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    c->ev_ks = true;
+    return TFHE_HIP_OK;
+}
+
+int tfhe_hip_last_kernel_ms(tfhe_hip_ctx *c, float *br_ms, float *ks_ms) {
+    if (int r = check_ctx(c, false)) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float a = 0.f, b = 0.f;
+    if (c->ev_br) HIPCHK(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    if (c->ev_ks) HIPCHK(hipEventElapsedTime(&b, c->ev[2], c->ev[3]));
+    if (br_ms) *br_ms = a;
+    if (ks_ms) *ks_ms = b;
+    return TFHE_HIP_OK;
+}
+
+// ---- host-buffer entry points -----------------------------------------------------------------------------------
+static int h2d(tfhe_hip_ctx *c, DevBuf &buf, const void *src, size_t bytes) {
+    HIPCHK(buf.reserve(bytes));
+    HIPCHK(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return TFHE_HIP_OK;
+}
+static int d2h(tfhe_hip_ctx *c, void *dst, const void *src, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TFHE_HIP_OK;
+}
+
+int tfhe_hip_gate_batch(tfhe_hip_ctx *c, int gate, int32_t *out, const int32_t *a, const int32_t *b, const int32_t *cc,
+                        int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || (count > 0 && !out)) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    const size_t bytes = (size_t) count * kCt * sizeof(int32_t);
+    if (a) if (int r = h2d(c, c->in_a, a, bytes)) return r;
+    if (b) if (int r = h2d(c, c->in_b, b, bytes)) return r;
+    if (cc) if (int r = h2d(c, c->in_c, cc, bytes)) return r;
+    HIPCHK(c->outb.reserve(bytes));
+    if (int r = tfhe_hip_gate_batch_dev(c, gate, (int32_t *) c->outb.p, a ? (const int32_t *) c->in_a.p : nullptr,
+                                        b ? (const int32_t *) c->in_b.p : nullptr,
+                                        cc ? (const int32_t *) c->in_c.p : nullptr, count))
+        return r;
+    return d2h(c, out, c->outb.p, bytes);
+}
+
+int tfhe_hip_bootstrap_batch(tfhe_hip_ctx *c, int32_t *out, const int32_t *in, int32_t mu, int64_t count, int with_ks) {
+    if (int r = check_ctx(c, true)) return r;
+    if (count < 0 || (count > 0 && (!out || !in))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    const size_t ib = (size_t) count * kCt * sizeof(int32_t);
+    const size_t ob = (size_t) count * (with_ks ? kCt : kExt) * sizeof(int32_t);
+    if (int r = h2d(c, c->in_a, in, ib)) return r;
+    HIPCHK(c->outb.reserve(ob));
+    if (int r = tfhe_hip_bootstrap_batch_dev(c, (int32_t *) c->outb.p, (const int32_t *) c->in_a.p, mu, count, with_ks))
+        return r;
+    return d2h(c, out, c->outb.p, ob);
+}
+
+int tfhe_hip_keyswitch_batch(tfhe_hip_ctx *c, int32_t *out, const int32_t *in, int64_t count) {
+    if (int r = check_ctx(c, true)) return r;
+    if (count < 0 || (count > 0 && (!out || !in))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    const size_t ib = (size_t) count * kExt * sizeof(int32_t), ob = (size_t) count * kCt * sizeof(int32_t);
+    if (int r = h2d(c, c->in_a, in, ib)) return r;
+    HIPCHK(c->outb.reserve(ob));
+    if (int r = tfhe_hip_keyswitch_batch_dev(c, (int32_t *) c->outb.p, (const int32_t *) c->in_a.p, count)) return r;
+    return d2h(c, out, c->outb.p, ob);
+}
+
+static int raw_br(tfhe_hip_ctx *c, int mode, int32_t *acc, const int32_t *aux, size_t aux_elems, int64_t count) {
+    if (int r = check_ctx(c, true)) return r;
+    if (count < 0 || (count > 0 && (!acc || !aux))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    if (mode == MODE_EXTMUL)
+        for (int64_t i = 0; i < count; i++)
+            if (aux[i] < 0 || aux[i] >= kLwe) return fail(TFHE_HIP_ERR_ARG, "key index out of range");
+    const size_t ab = (size_t) count * 2 * kN * sizeof(int32_t);
+    if (int r = h2d(c, c->in_a, acc, ab)) return r;
+    if (int r = h2d(c, c->in_b, aux, aux_elems * sizeof(int32_t))) return r;
+    BrArgs A{};
+    A.acc_io = (int32_t *) c->in_a.p; A.bara = (const int32_t *) c->in_b.p; A.bk = c->bk; A.tw = c->tw; A.B = count;
+    c->ev_br = c->ev_ks = false;
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    if (int r = (mode == MODE_RAW ? launch_br<MODE_RAW>(c, A) : launch_br<MODE_EXTMUL>(c, A))) return r;
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    c->ev_br = true;
+    return d2h(c, acc, c->in_a.p, ab);
+}
+int tfhe_hip_blind_rotate_batch(tfhe_hip_ctx *c, int32_t *acc, const int32_t *bara, int64_t count) {
+    return raw_br(c, MODE_RAW, acc, bara, (size_t) (count > 0 ? count : 0) * kLwe, count);
+}
+int tfhe_hip_extern_mul_batch(tfhe_hip_ctx *c, int32_t *acc, const int32_t *key_index, int64_t count) {
+    return raw_br(c, MODE_EXTMUL, acc, key_index, (size_t) (count > 0 ? count : 0), count);
+}
+
+static int fwd_batch(tfhe_hip_ctx *c, double *spectra, const int32_t *polys, int64_t count, int torus) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || (count > 0 && (!spectra || !polys))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    const size_t pb = (size_t) count * kN * sizeof(int32_t), sb = (size_t) count * kNh * sizeof(c64);
+    if (int r = h2d(c, c->in_a, polys, pb)) return r;
+    HIPCHK(c->outb.reserve(sb));
+    HIPCHK(hipFuncSetAttribute((const void *) k_poly_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
+    hipLaunchKernelGGL(k_poly_fwd, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream,
+                       (const int32_t *) c->in_a.p, (c64 *) c->outb.p, (const c64 *) c->tw, (long long) count, torus);
+    HIPCHK(hipGetLastError());
+    return d2h(c, spectra, c->outb.p, sb);
+}
+int tfhe_hip_int_ifft_batch(tfhe_hip_ctx *c, double *spectra, const int32_t *polys, int64_t count) {
+    return fwd_batch(c, spectra, polys, count, 0);
+}
+int tfhe_hip_torus_ifft_batch(tfhe_hip_ctx *c, double *spectra, const int32_t *polys, int64_t count) {
+    return fwd_batch(c, spectra, polys, count, 1);
+}
+int tfhe_hip_torus_fft_batch(tfhe_hip_ctx *c, int32_t *polys, const double *spectra, int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || (count > 0 && (!spectra || !polys))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    const size_t pb = (size_t) count * kN * sizeof(int32_t), sb = (size_t) count * kNh * sizeof(c64);
+    if (int r = h2d(c, c->in_a, spectra, sb)) return r;
+    HIPCHK(c->outb.reserve(pb));
+    HIPCHK(hipFuncSetAttribute((const void *) k_poly_inv, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
+    hipLaunchKernelGGL(k_poly_inv, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream,
+                       (const c64 *) c->in_a.p, (int32_t *) c->outb.p, (const c64 *) c->tw, (long long) count);
+    HIPCHK(hipGetLastError());
+    return d2h(c, polys, c->outb.p, pb);
+}
+int tfhe_hip_negacyclic_mul_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_i, const int32_t *d_t,
+                                      int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || (count > 0 && (!d_out || !d_i || !d_t))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    HIPCHK(hipFuncSetAttribute((const void *) k_poly_mul, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
+    hipLaunchKernelGGL(k_poly_mul, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream, d_i, d_t, d_out,
+                       (const c64 *) c->tw, (long long) count);
+    HIPCHK(hipGetLastError());
+    return TFHE_HIP_OK;
+}
+int tfhe_hip_negacyclic_mul_batch(tfhe_hip_ctx *c, int32_t *out, const int32_t *ip, const int32_t *tp, int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || (count > 0 && (!out || !ip || !tp))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    const size_t pb = (size_t) count * kN * sizeof(int32_t);
+    if (int r = h2d(c, c->in_a, ip, pb)) return r;
+    if (int r = h2d(c, c->in_b, tp, pb)) return r;
+    HIPCHK(c->outb.reserve(pb));
+    if (int r = tfhe_hip_negacyclic_mul_batch_dev(c, (int32_t *) c->outb.p, (const int32_t *) c->in_a.p,
+                                                  (const int32_t *) c->in_b.p, count))
+        return r;
+    return d2h(c, out, c->outb.p, pb);
+}
+
+}  // extern "C"

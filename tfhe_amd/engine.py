@@ -1,0 +1,243 @@
+"""ctypes binding of libtfhe_hip.so (include/tfhe_hip.h).  No CPU fallback: if the library or a GPU is missing,
+constructing an Engine raises."""
+import ctypes
+import enum
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtfhe_hip.so")
+
+
+class PARAMS:
+    n = 630
+    N = 1024
+    k = 1
+    l = 3
+    Bgbit = 7
+    kpl = 6
+    ks_t = 8
+    ks_basebit = 2
+    ks_base = 4
+    MU = 1 << 29
+
+
+class Gate(enum.IntEnum):
+    NAND = 0
+    OR = 1
+    AND = 2
+    XOR = 3
+    XNOR = 4
+    NOR = 5
+    ANDNY = 6
+    ANDYN = 7
+    ORNY = 8
+    ORYN = 9
+    MUX = 10
+    NOT = 11
+    COPY = 12
+    CONST1 = 13
+    CONST0 = 14
+
+
+class TfheHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+EXPORTS = [
+    "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_load_keys_coef", "tfhe_hip_load_keys_fft",
+    "tfhe_hip_get_bkfft", "tfhe_hip_gate_batch", "tfhe_hip_bootstrap_batch", "tfhe_hip_keyswitch_batch",
+    "tfhe_hip_gate_batch_dev", "tfhe_hip_bootstrap_batch_dev", "tfhe_hip_keyswitch_batch_dev", "tfhe_hip_sync",
+    "tfhe_hip_stream", "tfhe_hip_last_kernel_ms", "tfhe_hip_blind_rotate_batch", "tfhe_hip_extern_mul_batch",
+    "tfhe_hip_int_ifft_batch", "tfhe_hip_torus_ifft_batch", "tfhe_hip_torus_fft_batch",
+    "tfhe_hip_negacyclic_mul_batch", "tfhe_hip_negacyclic_mul_batch_dev",
+]
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TfheHipError("%s not built: run `python -m tfhe_amd.build`" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.tfhe_hip_last_error.restype = ctypes.c_char_p
+        lib.tfhe_hip_stream.restype = ctypes.c_void_p
+        _lib = lib
+    return _lib
+
+
+def _p(arr):
+    return None if arr is None else ctypes.c_void_p(arr.ctypes.data)
+
+
+def _i32(arr, shape_tail):
+    if arr is None:
+        return None
+    a = np.ascontiguousarray(arr, dtype=np.int32)
+    if a.ndim < 1 or tuple(a.shape[-len(shape_tail):]) != tuple(shape_tail):
+        raise ValueError("expected trailing shape %r, got %r" % (shape_tail, a.shape))
+    return a.reshape((-1,) + tuple(shape_tail))
+
+
+class Engine:
+    """One engine = one tfhe_hip_ctx = one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        ctx = ctypes.c_void_p()
+        rc = self.lib.tfhe_hip_create(ctypes.byref(ctx), int(device))
+        if rc != 0:
+            raise TfheHipError("tfhe_hip_create(%d): %s" % (device, self.lib.tfhe_hip_last_error().decode()))
+        self.ctx = ctx
+        self.device = device
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.tfhe_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise TfheHipError("%s failed (%d): %s" % (what, rc, self.lib.tfhe_hip_last_error().decode()))
+
+    # ---- keys ----
+    def load_keys_coef(self, bk_coef, ks):
+        P = PARAMS
+        bk = _i32(bk_coef, (P.n, P.kpl, 2, P.N))
+        k = _i32(ks, (P.N, P.ks_t, P.ks_base, P.n + 1))
+        self._chk(self.lib.tfhe_hip_load_keys_coef(self.ctx, _p(bk), _p(k)), "load_keys_coef")
+
+    def load_keys_fft(self, bkfft, ks):
+        P = PARAMS
+        bk = np.ascontiguousarray(bkfft, dtype=np.float64)
+        assert bk.size == P.n * P.kpl * 2 * P.N
+        k = _i32(ks, (P.N, P.ks_t, P.ks_base, P.n + 1))
+        self._chk(self.lib.tfhe_hip_load_keys_fft(self.ctx, _p(bk), _p(k)), "load_keys_fft")
+
+    def get_bkfft(self):
+        P = PARAMS
+        out = np.empty((P.n, P.kpl, 2, P.N // 2, 2), dtype=np.float64)
+        self._chk(self.lib.tfhe_hip_get_bkfft(self.ctx, _p(out)), "get_bkfft")
+        return out
+
+    # ---- gates, host buffers ----
+    def gate_batch(self, gate, a=None, b=None, c=None, count=None):
+        P = PARAMS
+        a, b, c = (_i32(x, (P.n + 1,)) for x in (a, b, c))
+        if count is None:
+            count = a.shape[0]
+        out = np.empty((count, P.n + 1), dtype=np.int32)
+        self._chk(self.lib.tfhe_hip_gate_batch(self.ctx, int(gate), _p(out), _p(a), _p(b), _p(c),
+                                               ctypes.c_int64(count)), "gate_batch")
+        return out
+
+    def bootstrap_batch(self, x, mu=PARAMS.MU, with_ks=True):
+        P = PARAMS
+        x = _i32(x, (P.n + 1,))
+        out = np.empty((x.shape[0], (P.n if with_ks else P.N) + 1), dtype=np.int32)
+        self._chk(self.lib.tfhe_hip_bootstrap_batch(self.ctx, _p(out), _p(x), ctypes.c_int32(mu),
+                                                    ctypes.c_int64(x.shape[0]), int(bool(with_ks))), "bootstrap_batch")
+        return out
+
+    def keyswitch_batch(self, u):
+        P = PARAMS
+        u = _i32(u, (P.N + 1,))
+        out = np.empty((u.shape[0], P.n + 1), dtype=np.int32)
+        self._chk(self.lib.tfhe_hip_keyswitch_batch(self.ctx, _p(out), _p(u), ctypes.c_int64(u.shape[0])),
+                  "keyswitch_batch")
+        return out
+
+    # ---- device-resident (torch tensors or raw device pointers) ----
+    @staticmethod
+    def _dptr(t):
+        if t is None:
+            return None
+        if isinstance(t, int):
+            return ctypes.c_void_p(t)
+        return ctypes.c_void_p(t.data_ptr())
+
+    def gate_batch_dev(self, gate, out, a=None, b=None, c=None, count=None):
+        self._chk(self.lib.tfhe_hip_gate_batch_dev(self.ctx, int(gate), self._dptr(out), self._dptr(a), self._dptr(b),
+                                                   self._dptr(c), ctypes.c_int64(count)), "gate_batch_dev")
+
+    def bootstrap_batch_dev(self, out, x, count, mu=PARAMS.MU, with_ks=True):
+        self._chk(self.lib.tfhe_hip_bootstrap_batch_dev(self.ctx, self._dptr(out), self._dptr(x), ctypes.c_int32(mu),
+                                                        ctypes.c_int64(count), int(bool(with_ks))),
+                  "bootstrap_batch_dev")
+
+    def keyswitch_batch_dev(self, out, u, count):
+        self._chk(self.lib.tfhe_hip_keyswitch_batch_dev(self.ctx, self._dptr(out), self._dptr(u),
+                                                        ctypes.c_int64(count)), "keyswitch_batch_dev")
+
+    def negacyclic_mul_dev(self, out, ipolys, tpolys, count):
+        self._chk(self.lib.tfhe_hip_negacyclic_mul_batch_dev(self.ctx, self._dptr(out), self._dptr(ipolys),
+                                                             self._dptr(tpolys), ctypes.c_int64(count)),
+                  "negacyclic_mul_batch_dev")
+
+    def sync(self):
+        self._chk(self.lib.tfhe_hip_sync(self.ctx), "sync")
+
+    def stream(self):
+        return self.lib.tfhe_hip_stream(self.ctx)
+
+    def last_kernel_ms(self):
+        br, ks = ctypes.c_float(), ctypes.c_float()
+        self._chk(self.lib.tfhe_hip_last_kernel_ms(self.ctx, ctypes.byref(br), ctypes.byref(ks)), "last_kernel_ms")
+        return br.value, ks.value
+
+    # ---- stages ----
+    def blind_rotate_batch(self, acc, bara):
+        P = PARAMS
+        acc = _i32(acc, (2, P.N)).copy()
+        bara = _i32(bara, (P.n,))
+        self._chk(self.lib.tfhe_hip_blind_rotate_batch(self.ctx, _p(acc), _p(bara), ctypes.c_int64(acc.shape[0])),
+                  "blind_rotate_batch")
+        return acc
+
+    def extern_mul_batch(self, acc, key_index):
+        P = PARAMS
+        acc = _i32(acc, (2, P.N)).copy()
+        idx = np.ascontiguousarray(key_index, dtype=np.int32).reshape(-1)
+        assert idx.shape[0] == acc.shape[0]
+        self._chk(self.lib.tfhe_hip_extern_mul_batch(self.ctx, _p(acc), _p(idx), ctypes.c_int64(acc.shape[0])),
+                  "extern_mul_batch")
+        return acc
+
+    def int_ifft(self, polys):
+        return self._fwd(polys, self.lib.tfhe_hip_int_ifft_batch, "int_ifft_batch")
+
+    def torus_ifft(self, polys):
+        return self._fwd(polys, self.lib.tfhe_hip_torus_ifft_batch, "torus_ifft_batch")
+
+    def _fwd(self, polys, fn, what):
+        P = PARAMS
+        polys = _i32(polys, (P.N,))
+        out = np.empty((polys.shape[0], P.N // 2, 2), dtype=np.float64)
+        self._chk(fn(self.ctx, _p(out), _p(polys), ctypes.c_int64(polys.shape[0])), what)
+        return out
+
+    def torus_fft(self, spectra):
+        P = PARAMS
+        s = np.ascontiguousarray(spectra, dtype=np.float64).reshape(-1, P.N // 2, 2)
+        out = np.empty((s.shape[0], P.N), dtype=np.int32)
+        self._chk(self.lib.tfhe_hip_torus_fft_batch(self.ctx, _p(out), _p(s), ctypes.c_int64(s.shape[0])),
+                  "torus_fft_batch")
+        return out
+
+    def negacyclic_mul(self, ipolys, tpolys):
+        P = PARAMS
+        a, b = _i32(ipolys, (P.N,)), _i32(tpolys, (P.N,))
+        assert a.shape == b.shape
+        out = np.empty_like(a)
+        self._chk(self.lib.tfhe_hip_negacyclic_mul_batch(self.ctx, _p(out), _p(a), _p(b), ctypes.c_int64(a.shape[0])),
+                  "negacyclic_mul_batch")
+        return out
