@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py - bootstrapped gates/s on MI355X (BASELINE.json metric), one process per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+              bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (bootsNAND: pre-combination, modulus switch, blind rotation, extraction,
+keyswitch) over one batch of B = 16384 independent gates per GPU (BASELINE.json configs[1]); inputs and outputs are
+resident in HBM, keys are uploaded once before timing.  Gates shard across ranks with no data-path collective
+(weak scaling: every rank processes its own B gates); the only collective is the one-time key broadcast (RCCL).
+
+Rank 0 prints ONE JSON line; besides the contract fields it carries
+  roofline      dominant kernel (k_blind_rotate): algorithmic FP64 flop per launch (1.626e8 per
+                bootstrap x B) / average launch duration from HIP events on the kernel's stream, against the
+                78.6 TFLOP/s FP64 vector peak of MI355X
+  cpu_baseline  the reference itself (oracle/_ref, kind "reference") or the C restatement (oracle/, kind "port")
+                timed on this box's host cores over a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_BOOTSTRAP = 162570240.0   # 630 x (8 x 26,112 + 49,152)
+FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak (vendor spec)
+
+
+def cpu_baseline(keys, ca, cb, expect_bits, client):
+    """times NAND gates on the host cores: the reference build if it travelled here, else the oracle port"""
+    import ctypes
+    from tests.oracle_lib import Oracle, REF_SO, P
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    threads = max(1, min(threads, 64))
+    per_thread = 4
+    count = threads * per_thread
+    a, b = np.ascontiguousarray(ca[:count]), np.ascontiguousarray(cb[:count])
+    out = np.zeros_like(a)
+    kind = "port"
+    if os.path.exists(REF_SO):
+        try:
+            ref = ctypes.CDLL(REF_SO)
+            ref.ref_set_keys(P(keys.lwe_key), P(keys.tlwe_key), P(keys.bk_coef), P(keys.ks))
+            t0 = time.perf_counter()
+            ref.ref_gate_batch(0, P(out), P(a), P(b), None, ctypes.c_longlong(count), ctypes.c_int32(threads))
+            dt = time.perf_counter() - t0
+            kind = "reference"
+        except OSError:
+            kind = "port"
+    if kind == "port":
+        orc = Oracle()
+        ok = orc.keys_from_coef(keys.bk_coef, keys.ks)
+        t0 = time.perf_counter()
+        out = orc.gate_batch(ok, 0, a, b, nthreads=threads)
+        dt = time.perf_counter() - t0
+    bits, _ = client.decrypt(keys, out)
+    if not np.array_equal(bits, expect_bits[:count]):
+        raise RuntimeError("cpu baseline produced wrong gate outputs")
+    return {"value": count / dt, "unit": "gates/s", "cores": threads, "kind": kind,
+            "sample": "%d bootsNAND gates, %d per thread on %d threads, %.1f s wall (%.1f ms/gate/core)"
+                      % (count, per_thread, threads, dt, 1e3 * dt * threads / count)}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16384, help="gates per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tfhe_amd import Client, Engine, Gate, PARAMS as PR
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    client = Client()
+    # ---- keys: generated once (rank 0), replicated to every GPU by an RCCL broadcast -------------------------
+    if rank == 0:
+        keys = client.keygen(42)
+    if world > 1:
+        from tfhe_amd.client import KeySet
+        shapes = {"lwe_key": (PR.n,), "tlwe_key": (PR.N,), "bk_coef": (PR.n, PR.kpl, 2, PR.N),
+                  "ks": (PR.N, PR.ks_t, PR.ks_base, PR.n + 1)}
+        parts = {}
+        for name, shp in shapes.items():
+            t = torch.from_numpy(getattr(keys, name)).to(dev) if rank == 0 else torch.empty(shp, dtype=torch.int32,
+                                                                                          device=dev)
+            dist.broadcast(t, src=0)
+            parts[name] = t.cpu().numpy()
+            del t
+        keys = KeySet(42, **parts)
+    eng = Engine(local_rank)
+    eng.load_keys_coef(keys.bk_coef, keys.ks)
+
+    # ---- synthetic inputs: fresh encryptions of iid random bits, resident in HBM -----------------------------
+    B = args.batch
+    rng = np.random.default_rng(1000 + rank)
+    bits_a = rng.integers(0, 2, B).astype(np.uint8)
+    bits_b = rng.integers(0, 2, B).astype(np.uint8)
+    ca = client.encrypt(keys, bits_a, seed=2000 + 2 * rank)
+    cb = client.encrypt(keys, bits_b, seed=2001 + 2 * rank)
+    expect = (1 - (bits_a & bits_b)).astype(np.uint8)
+    d_a = torch.from_numpy(ca).to(dev)
+    d_b = torch.from_numpy(cb).to(dev)
+    d_out = torch.empty((B, PR.n + 1), dtype=torch.int32, device=dev)
+
+    def step():
+        eng.gate_batch_dev(Gate.NAND, d_out, d_a, d_b, None, count=B)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    br_ms, ks_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        b_, k_ = eng.last_kernel_ms()   # HIP events on the engine's stream; waits for this step's kernels
+        br_ms.append(b_)
+        ks_ms.append(k_)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness of what was timed (outside the timed region) --------------------------------------------
+    got = d_out.cpu().numpy()
+    dec, phases = client.decrypt(keys, got)
+    n_bad = int((dec != expect).sum())
+    ok_flag = torch.tensor([n_bad], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(ok_flag)
+    total_bad = int(ok_flag.item())
+
+    # per-gate latency: batch of 1 on one GPU
+    lat_ms = None
+    if rank == 0:
+        eng.gate_batch_dev(Gate.NAND, d_out, d_a, d_b, None, count=1)
+        eng.sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            eng.gate_batch_dev(Gate.NAND, d_out, d_a, d_b, None, count=1)
+            eng.sync()
+        lat_ms = (time.perf_counter() - t1) / 3 * 1e3
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, cpu_out = cpu_baseline(keys, ca, cb, expect, client)
+        # the GPU's ciphertexts are the CPU path's ciphertexts, bit for bit
+        if not np.array_equal(cpu_out, got[:cpu_out.shape[0]]):
+            raise RuntimeError("GPU ciphertexts differ from the CPU path's")
+
+    if rank == 0:
+        if total_bad:
+            raise SystemExit("FAILED: %d of %d gate outputs decrypt wrongly" % (total_bad, B * world))
+        ms_per_step = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        br_avg = float(np.mean(br_ms))
+        achieved = FLOP_PER_BOOTSTRAP * B / (br_avg * 1e-3) / 1e12
+        traffic = None
+        tr_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr_file):
+            with open(tr_file) as f:
+                traffic = json.load(f).get("k_blind_rotate_hbm_bytes_per_launch")
+        line = {
+            "metric": "bootstrapped gates/sec (n=630 N=1024 l=3 Bgbit=7, bootsNAND)", "value": value,
+            "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "batch of %d independent bootsNAND gates per GPU (BASELINE configs[1])" % B,
+                       "gates_per_gpu_per_step": B, "parallelism": "gates sharded over %d GPU(s), keys replicated" % world,
+                       "outputs_decrypt_correctly": True},
+            "per_gate_latency_ms": lat_ms,
+            "kernel_ms": {"blind_rotate": br_avg, "keyswitch": float(np.mean(ks_ms))},
+            "roofline": {"bound": "fp64_valu", "kernel": "k_blind_rotate", "achieved": achieved,
+                         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "flop_per_launch": FLOP_PER_BOOTSTRAP * B, "launch_ms": br_avg},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

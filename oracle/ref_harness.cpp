@@ -300,3 +300,29 @@ int32_t ref_modswitch_from(int32_t phase, int32_t Msize) { return modSwitchFromT
 int32_t ref_modswitch_to(int32_t mu, int32_t Msize) { return modSwitchToTorus32(mu, Msize); }
 
 }  // extern "C"
+
+// ---- multi-threaded batch driver over the reference's bootsNAND... (cpu_baseline "reference" leg of bench.py) ----
+#include <pthread.h>
+namespace {
+struct RefJob { int32_t gate; int32_t *out; const int32_t *a, *b, *c; long long i0, i1; };
+void *ref_worker(void *arg) {
+    RefJob *j = (RefJob *) arg;
+    const long long s = n_ + 1;
+    for (long long i = j->i0; i < j->i1; i++)
+        ref_gate(j->gate, j->out + i * s, j->a ? j->a + i * s : nullptr, j->b ? j->b + i * s : nullptr,
+                 j->c ? j->c + i * s : nullptr);
+    return nullptr;
+}
+}
+extern "C" void ref_gate_batch(int32_t gate, int32_t *out, const int32_t *a, const int32_t *b, const int32_t *c,
+                               long long count, int32_t nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    RefJob jobs[256];
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = RefJob{gate, out, a, b, c, count * t / nthreads, count * (t + 1) / nthreads};
+        pthread_create(&th[t], nullptr, ref_worker, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], nullptr);
+}
