@@ -30,7 +30,8 @@ static void emu_forward(const double *p, c64 *logical_out) {
     static c64 v[64][8], scratch[512];
     TW tw;
     for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) { int j = (br3(r) << 6) | l; v[l][r] = {p[j], p[j + 512]}; }
-    for (int l = 0; l < 64; l++) fwd_phaseA(v[l], tw);
+    const PhaseAConsts kc = make_phaseA_consts(tw);
+    for (int l = 0; l < 64; l++) fwd_phaseA(v[l], kc);
     for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) scratch[swz(fwd_xA(l, r))] = v[l][r];
     for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) v[l][r] = scratch[swz(fwd_xB(l, r))];
     for (int l = 0; l < 64; l++) fwd_phaseB(v[l], l, tw);
@@ -40,21 +41,22 @@ static void emu_forward(const double *p, c64 *logical_out) {
     for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) logical_out[igray(fwd_xC(l, r))] = v[l][r];
 }
 
-static void emu_inverse(const c64 *C /*logical*/, int32_t *out) {
+static void emu_inverse(const c64 *C /*logical*/, int32_t *out, bool bounded) {
     static c64 v[64][16], scratch[1024];
     TW tw;
     for (int l = 0; l < 64; l++) for (int rho = 0; rho < 16; rho++) {
         int m = (br4(rho) << 6) | l;
         v[l][rho] = m < 512 ? C[m] : c64{C[1023 - m].re, -C[1023 - m].im};
     }
-    for (int l = 0; l < 64; l++) inv_phaseA(v[l], tw);
+    const PhaseAConsts kc = make_phaseA_consts(tw);
+    for (int l = 0; l < 64; l++) inv_phaseA(v[l], kc);
     for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) scratch[inv_yA(l, r)] = v[l][r];
     for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) v[l][r] = scratch[inv_yB(l, r)];
     for (int l = 0; l < 64; l++) inv_phaseB(v[l], l, tw);
     for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) scratch[inv_yB(l, r)] = v[l][r];
     for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) v[l][r] = scratch[inv_yC(l, r)];
     for (int l = 0; l < 64; l++) inv_phaseC(v[l], l, tw);
-    for (int l = 0; l < 64; l++) { int32_t o[16]; inv_final(o, v[l], l, tw); for (int r = 0; r < 16; r++) out[inv_yC(l, r)] = o[r]; }
+    for (int l = 0; l < 64; l++) { int32_t o[16]; if (bounded) inv_final<true>(o, v[l], l, tw); else inv_final<false>(o, v[l], l, tw); for (int r = 0; r < 16; r++) out[inv_yC(l, r)] = o[r]; }
 }
 
 int main() {
@@ -84,9 +86,15 @@ int main() {
         for (int i = 0; i < 512; i++) { C[i] = {got[i].re * scale, got[i].im * scale}; Cd[2*i] = C[i].re; Cd[2*i+1] = C[i].im; }
         int32_t r1[1024], r2[1024];
         oracle_TorusPolynomial_fft(r1, Cd);
-        emu_inverse(C, r2);
+        emu_inverse(C, r2, false);
         { int nd = 0; for (int i = 0; i < 1024; i++) if (r1[i] != r2[i]) nd++;
           if (nd) { bad++; if (bad < 8) printf("inverse trial %d: %d coefficients differ\n", trial, nd); } }
+        // bounded-range truncation (valid below 2^51): spectrum scaled so that the output stays below 2^50
+        for (int i = 0; i < 512; i++) { C[i] = {got[i].re * 2000.0, got[i].im * 2000.0}; Cd[2*i] = C[i].re; Cd[2*i+1] = C[i].im; }
+        oracle_TorusPolynomial_fft(r1, Cd);
+        emu_inverse(C, r2, true);
+        { int nd = 0; for (int i = 0; i < 1024; i++) if (r1[i] != r2[i]) nd++;
+          if (nd) { bad++; if (bad < 8) printf("inverse(bounded) trial %d: %d coefficients differ\n", trial, nd); } }
     }
     printf(bad ? "EMU FAIL (%d)\n" : "EMU OK\n", bad);
     return bad != 0;

@@ -65,9 +65,11 @@ BRC_HD constexpr int igray(int u) {
 }
 BRC_HD constexpr int gray(int u) { return u ^ (u >> 1); }
 
-// ---- LDS scratch swizzles (slot = 16-byte element index inside the wave's 8 KB scratch) -------------------
-// chosen so that the ds_write_b128 / ds_read_b128 of the transposes below are bank-conflict free or 2-way
-BRC_HD int swz(int x) { return x ^ ((x >> 3) & 7) ^ (((x >> 6) & 1) << 3); }
+// ---- LDS scratch swizzle (slot = 16-byte element index inside the wave's 8 KB scratch) ------------------------
+// XORs slot bits 6..8 into bits 0..2 and bit 7 into bit 3.  With it every ds_write_b128 / ds_read_b128 of the three
+// layouts used below (A: x = br6(l)<<3|r, B: x = (l>>3)<<6|r<<3|(l&7), C: x = r<<6|l) and of the Gray-ordered read
+// that feeds the inverse transform is bank-conflict free under the gfx950 lane-group rules (tools/lds_sim.py).
+BRC_HD int swz(int x) { return x ^ ((x >> 6) & 7) ^ (((x >> 7) & 1) << 3); }
 
 // ---- butterflies ---------------------------------------------------------------------------------------------
 // forward ("reverse" table of the reference, polynomials.cpp:78-85 with s = -sin):
@@ -98,19 +100,40 @@ BRC_HD void inv_bf(c64 &E, c64 &O, const c64 w) {
 //   input of phase A:  v[r] = p[j] + i p[j+512],  j = br9(x) = br3(r)<<6 | l
 //   output of phase C: v[r] = P(omega^(2i+1)),    i = igray(x)         (reference LagrangeHalfC index i)
 // =================================================================================================================
-template <class TW>  // TW: functor (index) -> c64 ; uniform indices
-BRC_HD void fwd_phaseA(c64 (&v)[8], const TW &tw) {
-    const c64 w8 = tw(tw_idx(8, 1));
+// The in-register phases (levels whose twiddles do not depend on the lane) need only seven distinct table values,
+// cos/sin of pi/4, pi/8, pi/16 and 3pi/16 (the table's octant folding makes cos(pi/2 - x) and sin(x) the same
+// double); they travel as kernel arguments, i.e. in scalar registers.
+struct PhaseAConsts {
+    double c4;        // table(8,1).re = table(8,1).im
+    double c8, s8;    // table(16,1)
+    double c16, s16;  // table(32,1)
+    double c316, s316;  // table(32,3)
+};
+template <class TW>
+BRC_HD PhaseAConsts make_phaseA_consts(const TW &tw) {
+    PhaseAConsts k;
+    k.c4 = tw(tw_idx(8, 1)).re;
+    k.c8 = tw(tw_idx(16, 1)).re;
+    k.s8 = tw(tw_idx(16, 1)).im;
+    k.c16 = tw(tw_idx(32, 1)).re;
+    k.s16 = tw(tw_idx(32, 1)).im;
+    k.c316 = tw(tw_idx(32, 3)).re;
+    k.s316 = tw(tw_idx(32, 3)).im;
+    return k;
+}
+
+BRC_HD void fwd_phaseA(c64 (&v)[8], const PhaseAConsts &k) {
+    const c64 w8 = {k.c4, k.c4};
 #pragma unroll
     for (int r = 0; r < 8; r += 2) fwd_bf(v[r], v[r + 1], w8);
-    const c64 w16a = tw(tw_idx(16, 1)), w16b = tw(tw_idx(16, 3));
+    const c64 w16a = {k.c8, k.s8}, w16b = {k.s8, k.c8};  // table(16,1), table(16,3)
 #pragma unroll
     for (int g = 0; g < 8; g += 4) {
         fwd_bf(v[g + 0], v[g + 2], w16a);
         fwd_bf(v[g + 1], v[g + 3], w16b);
     }
     // level 2 (size 32): u = r&3 -> igray = 0,1,3,2 -> q = 1,3,7,5
-    const c64 w32a = tw(tw_idx(32, 1)), w32b = tw(tw_idx(32, 3)), w32c = tw(tw_idx(32, 7)), w32d = tw(tw_idx(32, 5));
+    const c64 w32a = {k.c16, k.s16}, w32b = {k.c316, k.s316}, w32c = {k.s16, k.c16}, w32d = {k.s316, k.c316};
     fwd_bf(v[0], v[4], w32a);
     fwd_bf(v[1], v[5], w32b);
     fwd_bf(v[2], v[6], w32c);
@@ -193,34 +216,54 @@ BRC_HD int inv_yA(int lane, int rho) { return (br6(lane) << 4) | rho; }
 BRC_HD int inv_yB(int lane, int rho) { return ((lane >> 3) << 7) | ((rho >> 1) << 4) | ((rho & 1) << 3) | (lane & 7); }
 BRC_HD int inv_yC(int lane, int rho) { return ((rho >> 1) << 7) | ((lane >> 3) << 4) | ((rho & 1) << 3) | (lane & 7); }
 
-template <class TW>
-BRC_HD void inv_phaseA(c64 (&v)[16], const TW &tw) {
+// inverse butterflies with the special twiddles of the in-register levels.  Each is value-identical to inv_bf with
+// the table entry (products with 1, 0 and a negated cosine are exact rewrites: x*1 = x, x + y*0 = x up to the sign of
+// a zero, x*(-c) = -(x*c), -a + b = b - a).
+BRC_HD void inv_bf_one(c64 &E, c64 &O) {  // w = (1, 0)
+    const c64 lo = {E.re + O.re, E.im + O.im}, hi = {E.re - O.re, E.im - O.im};
+    E = lo;
+    O = hi;
+}
+BRC_HD void inv_bf_mi(c64 &E, c64 &O) {  // w = (-0, 1): t = (Oi, -Or)
+    const c64 lo = {E.re + O.im, E.im - O.re}, hi = {E.re - O.im, E.im + O.re};
+    E = lo;
+    O = hi;
+}
+BRC_HD void inv_bf_neg(c64 &E, c64 &O, const double c, const double s) {  // w = (-c, s)
+    const double tr = O.im * s - O.re * c;     // Or*(-c) + Oi*s
+    const double ti = -(O.im * c) - O.re * s;  // Oi*(-c) - Or*s
+    const c64 lo = {E.re + tr, E.im + ti}, hi = {E.re - tr, E.im - ti};
+    E = lo;
+    O = hi;
+}
+
+BRC_HD void inv_phaseA(c64 (&v)[16], const PhaseAConsts &k) {
     // level 0 (size 2, polynomials.cpp:113-122): plain sum / difference
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        const c64 a = v[r], b = v[r + 1];
-        v[r] = {a.re + b.re, a.im + b.im};
-        v[r + 1] = {a.re - b.re, a.im - b.im};
-    }
+    for (int r = 0; r < 16; r += 2) inv_bf_one(v[r], v[r + 1]);
     // level 1 (size 4, :125-145): even index plain, odd index twiddle -i
 #pragma unroll
     for (int g = 0; g < 16; g += 4) {
-        const c64 a = v[g], b = v[g + 2];
-        v[g] = {a.re + b.re, a.im + b.im};
-        v[g + 2] = {a.re - b.re, a.im - b.im};
-        const c64 c = v[g + 1], d = v[g + 3];
-        v[g + 1] = {c.re + d.im, c.im - d.re};
-        v[g + 3] = {c.re - d.im, c.im + d.re};
+        inv_bf_one(v[g], v[g + 2]);
+        inv_bf_mi(v[g + 1], v[g + 3]);
     }
-    // level 2 (size 8): j = y & 3
+    // level 2 (size 8): table(8, j) = (1,0), (c4,c4), (-0,1), (-c4,c4)
 #pragma unroll
     for (int g = 0; g < 16; g += 8) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) inv_bf(v[g + j], v[g + j + 4], tw(tw_idx(8, j)));
+        inv_bf_one(v[g + 0], v[g + 4]);
+        inv_bf(v[g + 1], v[g + 5], c64{k.c4, k.c4});
+        inv_bf_mi(v[g + 2], v[g + 6]);
+        inv_bf_neg(v[g + 3], v[g + 7], k.c4, k.c4);
     }
-    // level 3 (size 16): j = y & 7
-#pragma unroll
-    for (int j = 0; j < 8; j++) inv_bf(v[j], v[j + 8], tw(tw_idx(16, j)));
+    // level 3 (size 16): table(16, j) = (1,0), (c8,s8), (c4,c4), (s8,c8), (-0,1), (-s8,c8), (-c4,c4), (-c8,s8)
+    inv_bf_one(v[0], v[8]);
+    inv_bf(v[1], v[9], c64{k.c8, k.s8});
+    inv_bf(v[2], v[10], c64{k.c4, k.c4});
+    inv_bf(v[3], v[11], c64{k.s8, k.c8});
+    inv_bf_mi(v[4], v[12]);
+    inv_bf_neg(v[5], v[13], k.s8, k.c8);
+    inv_bf_neg(v[6], v[14], k.c4, k.c4);
+    inv_bf_neg(v[7], v[15], k.c8, k.s8);
 }
 
 template <class TW>
@@ -286,8 +329,18 @@ BRC_HD void inv_phaseC(c64 (&v)[16], int lane, const TW &tw) {
     }
 }
 
-// last merge (size 2048) + scaling + truncation: polynomials.cpp:160-166 with E = 0, then :392
-template <class TW>
+// last merge (size 2048) + scaling + truncation: polynomials.cpp:160-166 with E = 0, then :392.
+// BOUNDED = true may be used when |value| < 2^51 is guaranteed (inside the external product the value is a sum of
+// 6*1024 products of a digit in [-64,63] and a torus real in [-1/2,1/2), scaled by 2^32: below 2^50).  Then
+// trunc(x) + 1.5*2^52 is exact and the low mantissa word is trunc(x) mod 2^32 - the same bits as the reference's
+// Torus32(int64_t(x)) - at 2 instructions instead of a full f64 -> i64 conversion.
+BRC_HD int32_t trunc_to_torus32_bounded(double x) {
+    const double t = __builtin_trunc(x) + 6755399441055744.0;
+    uint64_t u;
+    __builtin_memcpy(&u, &t, 8);
+    return (int32_t) (uint32_t) u;
+}
+template <bool BOUNDED, class TW>
 BRC_HD void inv_final(int32_t (&out)[16], const c64 (&v)[16], int lane, const TW &tw) {
 #pragma unroll
     for (int rho = 0; rho < 16; rho++) {
@@ -295,7 +348,7 @@ BRC_HD void inv_final(int32_t (&out)[16], const c64 (&v)[16], int lane, const TW
         const c64 w = tw(tw_idx(2048, y));
         const double tr = v[rho].re * w.re + v[rho].im * w.im;
         const double scaled = tr * 4194304.0;  // (tr * 2^-10) * 2^32, both exact scalings
-        out[rho] = (int32_t) (uint32_t) (uint64_t) (int64_t) scaled;
+        out[rho] = BOUNDED ? trunc_to_torus32_bounded(scaled) : (int32_t) (uint32_t) (uint64_t) (int64_t) scaled;
     }
 }
 

@@ -36,10 +36,6 @@ constexpr int kKsT = 8, kKsBasebit = 2;
 // ---------------------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------------------
-struct TwUniform {  // compile-time / wave-uniform indices: read through the scalar cache from global memory
-    const c64 *t;
-    __device__ __forceinline__ c64 operator()(int i) const { return t[i]; }
-};
 struct TwLds {  // lane-dependent indices: read from the LDS copy of the table
     const c64 *t;
     __device__ __forceinline__ c64 operator()(int i) const { return t[i]; }
@@ -48,11 +44,11 @@ struct TwLds {  // lane-dependent indices: read from the LDS copy of the table
 // Exchanges between lanes of ONE wave go through LDS without a workgroup barrier: LDS operations of a wave are
 // executed in issue order, so only the compiler has to be kept from reordering them.
 __device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void wave_fwd(c64 (&v)[8], int lane, c64 *scratch, const TwUniform &twu, const TwLds &twl) {
+__device__ __forceinline__ void wave_fwd(c64 (&v)[8], int lane, c64 *scratch, const PhaseAConsts &twu, const TwLds &twl) {
     fwd_phaseA(v, twu);
 #pragma unroll
     for (int r = 0; r < 8; r++) scratch[swz(fwd_xA(lane, r))] = v[r];
@@ -73,8 +69,9 @@ __device__ __forceinline__ void wave_fwd(c64 (&v)[8], int lane, c64 *scratch, co
 // element index inside one half (fixed y3) of the 1024-entry inverse working array
 __device__ __forceinline__ int inv_elem(int y) { return ((y >> 4) << 3) | (y & 7); }
 
+template <bool BOUNDED>
 __device__ __forceinline__ void wave_inv(int32_t (&out)[16], c64 (&v)[16], int lane, c64 *scratch,
-                                         const TwUniform &twu, const TwLds &twl) {
+                                         const PhaseAConsts &twu, const TwLds &twl) {
     inv_phaseA(v, twu);
     c64 w[16];
     // layout A (regs y3y2y1y0) -> layout B (regs y6y5y4,y3), one half (y3) at a time through the 8 KB scratch
@@ -99,7 +96,7 @@ __device__ __forceinline__ void wave_inv(int32_t (&out)[16], c64 (&v)[16], int l
         wave_sync();
     }
     inv_phaseC(v, lane, twl);
-    inv_final(out, v, lane, twl);
+    inv_final<BOUNDED>(out, v, lane, twl);
 }
 
 // spectrum held as (lane, r) <-> physical slot x = r<<6|lane  ->  inverse-transform input registers, via scratch
@@ -144,6 +141,7 @@ struct BrArgs {
     const int32_t *bara;   // MODE_RAW: [B][n] rotation amounts; MODE_EXTMUL: [B] key index
     const c64 *bk;         // [n][6][2][8][64] physical slot order
     const c64 *tw;         // twiddle table, kTwEntries
+    PhaseAConsts ka;       // in-register-phase twiddles (scalar registers)
     long long B;
 };
 enum { MODE_GATE = 0, MODE_RAW = 1, MODE_EXTMUL = 2 };
@@ -157,7 +155,7 @@ constexpr int kBrLdsPerWave = 2 * kN * 4 + kNh * 16;  // accumulator + scratch =
 // EXTMUL variant: ACC <- bk_i (*) ACC (the external product alone).
 template <bool ROTATE>
 __device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int bara, const c64 *bki,
-                                     const TwUniform &twu, const TwLds &twl) {
+                                     const PhaseAConsts &twu, const TwLds &twl) {
     c64 tmpa[2][8];
 #pragma unroll
     for (int c = 0; c < 2; c++)
@@ -181,16 +179,23 @@ __device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int b
         }
 #pragma unroll 1
         for (int p = 0; p < kL; p++) {
+            // key row (c,p): 2 x 512 spectrum values, 16 x 16 B per lane, requested before the transform so that the
+            // L2/HBM latency hides behind it
+            const c64 *row = bki + (size_t) ((c * kL + p) * 2) * kNh + lane;
+            c64 kb[2][8];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) kb[c2][r] = row[c2 * kNh + r * 64];
             c64 v[8];
 #pragma unroll
             for (int r = 0; r < 8; r++)
                 v[r] = {(double) decomp_digit(tlo[r], p), (double) decomp_digit(thi[r], p)};
             wave_fwd(v, lane, scratch, twu, twl);
-            const c64 *row = bki + (size_t) ((c * kL + p) * 2) * kNh + lane;
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++)
 #pragma unroll
-                for (int r = 0; r < 8; r++) cmac(tmpa[c2][r], v[r], row[c2 * kNh + r * 64]);
+                for (int r = 0; r < 8; r++) cmac(tmpa[c2][r], v[r], kb[c2][r]);
         }
     }
 #pragma unroll 1
@@ -199,7 +204,7 @@ __device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int b
         int32_t res[16];
         if (c2 == 0) spectrum_to_inv_input(v, tmpa[0], lane, scratch);
         else spectrum_to_inv_input(v, tmpa[1], lane, scratch);
-        wave_inv(res, v, lane, scratch, twu, twl);
+        wave_inv<true>(res, v, lane, scratch, twu, twl);
         int32_t *accc = acc + c2 * kN;
 #pragma unroll
         for (int rho = 0; rho < 16; rho++) {
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
     c64 *scratch = reinterpret_cast<c64 *>(mine + 2 * kN * 4);
     const long long g = (long long) blockIdx.x * WAVES + wave;
     if (g >= A.B) return;  // wave-uniform; no workgroup barrier after this point
-    const TwUniform twu{A.tw};
+    const PhaseAConsts twu = A.ka;
     const TwLds twl{tw_lds};
 
     if (MODE == MODE_GATE) {
@@ -286,20 +291,26 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
 //   out = (0, b') - sum_{i<N, j<t} ks[i][j][digit_ij],  digit_ij = ((a'_i + 2^15) >> (30 - 2j)) & 3, digit 0 skipped
 // grid (ceil(B/G), 3), block 256: thread = one output coefficient q, G ciphertexts in registers.
 // ---------------------------------------------------------------------------------------------------------------
+// grid ceil(B/32), block 160: thread = 4 consecutive output coefficients (one 16-byte piece of every key row),
+// 32 ciphertexts in registers, so each key row fetched from L2 serves 32 ciphertexts.  The digit selects the row
+// through two lane-uniform bit masks (no divergence): sel = d1 ? (d0 ? row3 : row2) : (d0 ? row1 : 0).
 constexpr int kKsG = 32;
-__global__ __launch_bounds__(256) void k_keyswitch(const int32_t *__restrict__ in, const int32_t *__restrict__ ks,
+constexpr int kKsThreads = kKsRow / 4;  // 158
+__global__ __launch_bounds__(192) void k_keyswitch(const int32_t *__restrict__ in, const int32_t *__restrict__ ks,
                                                    int32_t *__restrict__ out, long long B) {
-    const int q = blockIdx.y * 256 + threadIdx.x;
-    const bool active = q <= kLwe;
-    const int qq = active ? q : kLwe;
+    const int t = threadIdx.x;
+    if (t >= kKsThreads) return;
     const long long g0 = (long long) blockIdx.x * kKsG;
-    uint32_t acc[kKsG];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 acc[kKsG];
 #pragma unroll
     for (int g = 0; g < kKsG; g++) {
         const long long gi = (g0 + g < B) ? g0 + g : B - 1;
-        acc[g] = (qq == kLwe) ? (uint32_t) in[gi * kExt + kN] : 0u;
+        acc[g] = u32x4{0u, 0u, 0u, 0u};
+        if (t == kKsThreads - 1) acc[g].z = (uint32_t) in[gi * kExt + kN];  // coefficient 630 = b
     }
     const uint32_t prec_offset = 1u << (32 - (1 + kKsBasebit * kKsT));
+    const u32x4 *rows = reinterpret_cast<const u32x4 *>(ks) + t;
 #pragma unroll 1
     for (int i = 0; i < kN; i++) {
         uint32_t abar[kKsG];
@@ -308,24 +319,28 @@ __global__ __launch_bounds__(256) void k_keyswitch(const int32_t *__restrict__ i
             const long long gi = (g0 + g < B) ? g0 + g : B - 1;
             abar[g] = (uint32_t) in[gi * kExt + i] + prec_offset;
         }
-        const int32_t *rows = ks + (size_t) i * kKsT * 3 * kKsRow + qq;
-#pragma unroll
+#pragma unroll 2
         for (int j = 0; j < kKsT; j++) {
-            const uint32_t r1 = (uint32_t) rows[(j * 3 + 0) * kKsRow];
-            const uint32_t r2 = (uint32_t) rows[(j * 3 + 1) * kKsRow];
-            const uint32_t r3 = (uint32_t) rows[(j * 3 + 2) * kKsRow];
+            const u32x4 *rp = rows + (size_t) (i * kKsT + j) * 3 * (kKsRow / 4);
+            const u32x4 r1 = rp[0], r2 = rp[kKsRow / 4], r3 = rp[2 * (kKsRow / 4)];
 #pragma unroll
             for (int g = 0; g < kKsG; g++) {
-                const uint32_t d = (abar[g] >> (30 - 2 * j)) & 3u;
-                const uint32_t sel = d == 1 ? r1 : (d == 2 ? r2 : (d == 3 ? r3 : 0u));
-                acc[g] -= sel;
+                const uint32_t m0 = (uint32_t) ((int32_t) (abar[g] << (1 + 2 * j)) >> 31);  // digit bit 0
+                const uint32_t m1 = (uint32_t) ((int32_t) (abar[g] << (2 * j)) >> 31);      // digit bit 1
+                const u32x4 lo = r1 & m0;
+                const u32x4 hi = (r3 & m0) | (r2 & ~m0);
+                acc[g] -= (hi & m1) | (lo & ~m1);
             }
         }
     }
-    if (active) {
 #pragma unroll
-        for (int g = 0; g < kKsG; g++)
-            if (g0 + g < B) out[(g0 + g) * kCt + q] = (int32_t) acc[g];
+    for (int g = 0; g < kKsG; g++) {
+        if (g0 + g >= B) break;
+        int32_t *o = out + (g0 + g) * kCt + 4 * t;
+        o[0] = (int32_t) acc[g].x;
+        o[1] = (int32_t) acc[g].y;
+        o[2] = (int32_t) acc[g].z;
+        if (4 * t + 3 < kCt) o[3] = (int32_t) acc[g].w;
     }
 }
 
@@ -357,7 +372,7 @@ __global__ void k_linear_gate(int32_t *out, const int32_t *a, int gate, int32_t 
 // tGswToFFTConvert (tgsw-fft-operations.cpp:52-57) = TorusPolynomial_ifft (polynomials.cpp:364-376) on each of
 // the n*6*2 polynomials; result stored in physical slot order [poly][r][lane]
 __global__ __launch_bounds__(256) void k_bk_convert(const int32_t *__restrict__ coef, c64 *__restrict__ bk,
-                                                    const c64 *__restrict__ tw, int npoly) {
+                                                    const c64 *__restrict__ tw, PhaseAConsts ka, int npoly) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
     load_tw_to_lds(tw_lds, tw);
@@ -373,7 +388,7 @@ __global__ __launch_bounds__(256) void k_bk_convert(const int32_t *__restrict__ 
         const int j = (br3(r) << 6) | lane;
         v[r] = {p[j] * s, p[j + kNh] * s};
     }
-    wave_fwd(v, lane, scratch, TwUniform{tw}, TwLds{tw_lds});
+    wave_fwd(v, lane, scratch, ka, TwLds{tw_lds});
 #pragma unroll
     for (int r = 0; r < 8; r++) bk[(size_t) poly * kNh + r * 64 + lane] = v[r];
 }
@@ -402,7 +417,7 @@ __global__ void k_ks_pack(int32_t *dst, const int32_t *src, long long rows) {
 // ---------------------------------------------------------------------------------------------------------------
 // IntPolynomial_ifft (polynomials.cpp:347) / TorusPolynomial_ifft (:364); spectra written in the reference order
 __global__ __launch_bounds__(256) void k_poly_fwd(const int32_t *__restrict__ polys, c64 *__restrict__ spectra,
-                                                  const c64 *__restrict__ tw, long long count, int torus) {
+                                                  const c64 *__restrict__ tw, PhaseAConsts ka, long long count, int torus) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
     load_tw_to_lds(tw_lds, tw);
@@ -418,13 +433,13 @@ __global__ __launch_bounds__(256) void k_poly_fwd(const int32_t *__restrict__ po
         const int j = (br3(r) << 6) | lane;
         v[r] = {p[j] * s, p[j + kNh] * s};
     }
-    wave_fwd(v, lane, scratch, TwUniform{tw}, TwLds{tw_lds});
+    wave_fwd(v, lane, scratch, ka, TwLds{tw_lds});
 #pragma unroll
     for (int r = 0; r < 8; r++) spectra[poly * kNh + igray(fwd_xC(lane, r))] = v[r];
 }
 // TorusPolynomial_fft (polynomials.cpp:378-393); spectra read in the reference order
 __global__ __launch_bounds__(256) void k_poly_inv(const c64 *__restrict__ spectra, int32_t *__restrict__ polys,
-                                                  const c64 *__restrict__ tw, long long count) {
+                                                  const c64 *__restrict__ tw, PhaseAConsts ka, long long count) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
     load_tw_to_lds(tw_lds, tw);
@@ -444,14 +459,14 @@ __global__ __launch_bounds__(256) void k_poly_inv(const c64 *__restrict__ spectr
         }
     }
     int32_t res[16];
-    wave_inv(res, v, lane, scratch, TwUniform{tw}, TwLds{tw_lds});
+    wave_inv<false>(res, v, lane, scratch, ka, TwLds{tw_lds});
 #pragma unroll
     for (int rho = 0; rho < 16; rho++) polys[poly * kN + inv_yC(lane, rho)] = res[rho];
 }
 // torusPolynomialMultFFT (polynomials.cpp:241-248): out = ipoly * tpoly
 __global__ __launch_bounds__(256) void k_poly_mul(const int32_t *__restrict__ ipolys, const int32_t *__restrict__ tpolys,
                                                   int32_t *__restrict__ out, const c64 *__restrict__ tw,
-                                                  long long count) {
+                                                  PhaseAConsts ka, long long count) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
     load_tw_to_lds(tw_lds, tw);
@@ -459,7 +474,7 @@ __global__ __launch_bounds__(256) void k_poly_mul(const int32_t *__restrict__ ip
     c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwEntries * sizeof(c64)) + wave * kNh;
     const long long poly = (long long) blockIdx.x * 4 + wave;
     if (poly >= count) return;
-    const TwUniform twu{tw};
+    const PhaseAConsts twu = ka;
     const TwLds twl{tw_lds};
     c64 a[8], b[8], prod[8];
 #pragma unroll
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(256) void k_poly_mul(const int32_t *__restrict__ ip
     c64 v[16];
     int32_t res[16];
     spectrum_to_inv_input(v, prod, lane, scratch);
-    wave_inv(res, v, lane, scratch, twu, twl);
+    wave_inv<false>(res, v, lane, scratch, twu, twl);
 #pragma unroll
     for (int rho = 0; rho < 16; rho++) out[poly * kN + inv_yC(lane, rho)] = res[rho];
 }
@@ -562,13 +577,14 @@ struct tfhe_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     c64 *tw = nullptr;
+    PhaseAConsts ka{};
     c64 *bk = nullptr;       // [n][6][2][512] physical order
     int32_t *ks = nullptr;   // [N][t][3][632]
     bool have_keys = false;
     DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // br start/stop, ks start/stop
     bool ev_br = false, ev_ks = false;
-    int br_waves = 4;
+    int br_waves = 8;
 };
 
 namespace {
@@ -599,8 +615,8 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A) {
 
 int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B) {
     if (B <= 0) return TFHE_HIP_OK;
-    dim3 grid((unsigned) ((B + kKsG - 1) / kKsG), 3);
-    hipLaunchKernelGGL(k_keyswitch, grid, dim3(256), 0, c->stream, d_in, c->ks, d_out, B);
+    dim3 grid((unsigned) ((B + kKsG - 1) / kKsG));
+    hipLaunchKernelGGL(k_keyswitch, grid, dim3(192), 0, c->stream, d_in, c->ks, d_out, B);
     HIPCHK(hipGetLastError());
     return TFHE_HIP_OK;
 }
@@ -661,6 +677,7 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     HIPCHK(hipSetDevice(device));
     tfhe_hip_ctx *c = new tfhe_hip_ctx();
     c->device = device;
+    c->ka = make_phaseA_consts([&](int i) { return tw[i]; });
     const char *w = getenv("TFHE_HIP_BR_WAVES");
     if (w && atoi(w) == 8) c->br_waves = 8;
     if (w && atoi(w) == 4) c->br_waves = 4;
@@ -709,7 +726,7 @@ int tfhe_hip_load_keys_coef(tfhe_hip_ctx *c, const int32_t *bk_coef, const int32
     HIPCHK(hipMemcpyAsync(c->misc.p, bk_coef, coef_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipFuncSetAttribute((const void *) k_bk_convert, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
     hipLaunchKernelGGL(k_bk_convert, dim3((npoly + 3) / 4), dim3(256), kFftLds, c->stream, (const int32_t *) c->misc.p,
-                       c->bk, (const c64 *) c->tw, npoly);
+                       c->bk, (const c64 *) c->tw, c->ka, npoly);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));  // misc is reused by upload_ks
     if (int r = upload_ks(c, ks)) return r;
@@ -766,7 +783,7 @@ int tfhe_hip_bootstrap_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const int32_t 
     }
     BrArgs A{};
     A.a = d_in; A.b = nullptr; A.sa = 1; A.sb = 0; A.cst = 0; A.mu = mu; A.out = ext;
-    A.bk = c->bk; A.tw = c->tw; A.B = count;
+    A.bk = c->bk; A.tw = c->tw; A.ka = c->ka; A.B = count;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     if (int r = launch_br<MODE_GATE>(c, A)) return r;
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
@@ -813,7 +830,7 @@ int tfhe_hip_gate_batch_dev(tfhe_hip_ctx *c, int gate, int32_t *d_out, const int
     }
     HIPCHK(c->ext1.reserve((size_t) count * kExt * sizeof(int32_t)));
     BrArgs A{};
-    A.mu = kMU; A.bk = c->bk; A.tw = c->tw; A.B = count;
+    A.mu = kMU; A.bk = c->bk; A.tw = c->tw; A.ka = c->ka; A.B = count;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     if (gate == TFHE_HIP_MUX) {  // boot-gates.cpp:329-370
         HIPCHK(c->ext2.reserve((size_t) count * kExt * sizeof(int32_t)));
@@ -915,7 +932,7 @@ static int raw_br(tfhe_hip_ctx *c, int mode, int32_t *acc, const int32_t *aux, s
     if (int r = h2d(c, c->in_a, acc, ab)) return r;
     if (int r = h2d(c, c->in_b, aux, aux_elems * sizeof(int32_t))) return r;
     BrArgs A{};
-    A.acc_io = (int32_t *) c->in_a.p; A.bara = (const int32_t *) c->in_b.p; A.bk = c->bk; A.tw = c->tw; A.B = count;
+    A.acc_io = (int32_t *) c->in_a.p; A.bara = (const int32_t *) c->in_b.p; A.bk = c->bk; A.tw = c->tw; A.ka = c->ka; A.B = count;
     c->ev_br = c->ev_ks = false;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     if (int r = (mode == MODE_RAW ? launch_br<MODE_RAW>(c, A) : launch_br<MODE_EXTMUL>(c, A))) return r;
@@ -939,7 +956,7 @@ static int fwd_batch(tfhe_hip_ctx *c, double *spectra, const int32_t *polys, int
     HIPCHK(c->outb.reserve(sb));
     HIPCHK(hipFuncSetAttribute((const void *) k_poly_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
     hipLaunchKernelGGL(k_poly_fwd, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream,
-                       (const int32_t *) c->in_a.p, (c64 *) c->outb.p, (const c64 *) c->tw, (long long) count, torus);
+                       (const int32_t *) c->in_a.p, (c64 *) c->outb.p, (const c64 *) c->tw, c->ka, (long long) count, torus);
     HIPCHK(hipGetLastError());
     return d2h(c, spectra, c->outb.p, sb);
 }
@@ -958,7 +975,7 @@ int tfhe_hip_torus_fft_batch(tfhe_hip_ctx *c, int32_t *polys, const double *spec
     HIPCHK(c->outb.reserve(pb));
     HIPCHK(hipFuncSetAttribute((const void *) k_poly_inv, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
     hipLaunchKernelGGL(k_poly_inv, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream,
-                       (const c64 *) c->in_a.p, (int32_t *) c->outb.p, (const c64 *) c->tw, (long long) count);
+                       (const c64 *) c->in_a.p, (int32_t *) c->outb.p, (const c64 *) c->tw, c->ka, (long long) count);
     HIPCHK(hipGetLastError());
     return d2h(c, polys, c->outb.p, pb);
 }
@@ -969,7 +986,7 @@ int tfhe_hip_negacyclic_mul_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const int
     if (count == 0) return TFHE_HIP_OK;
     HIPCHK(hipFuncSetAttribute((const void *) k_poly_mul, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
     hipLaunchKernelGGL(k_poly_mul, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream, d_i, d_t, d_out,
-                       (const c64 *) c->tw, (long long) count);
+                       (const c64 *) c->tw, c->ka, (long long) count);
     HIPCHK(hipGetLastError());
     return TFHE_HIP_OK;
 }
