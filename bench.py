@@ -92,20 +92,8 @@ def main():
 
     client = Client()
     # ---- keys: generated once (rank 0), replicated to every GPU by an RCCL broadcast -------------------------
-    if rank == 0:
-        keys = client.keygen(42)
-    if world > 1:
-        from tfhe_amd.client import KeySet
-        shapes = {"lwe_key": (PR.n,), "tlwe_key": (PR.N,), "bk_coef": (PR.n, PR.kpl, 2, PR.N),
-                  "ks": (PR.N, PR.ks_t, PR.ks_base, PR.n + 1)}
-        parts = {}
-        for name, shp in shapes.items():
-            t = torch.from_numpy(getattr(keys, name)).to(dev) if rank == 0 else torch.empty(shp, dtype=torch.int32,
-                                                                                          device=dev)
-            dist.broadcast(t, src=0)
-            parts[name] = t.cpu().numpy()
-            del t
-        keys = KeySet(42, **parts)
+    from tfhe_amd.parallel import broadcast_keys
+    keys = broadcast_keys(client.keygen(42) if rank == 0 else None, device=dev)
     eng = Engine(local_rank)
     eng.load_keys_coef(keys.bk_coef, keys.ks)
 

@@ -104,14 +104,7 @@ def test_bootstrap_bit_exact(engine, oracle, okeys, client, keys):
     assert np.array_equal(dec, bits)
 
 
-TRUTH = {
-    Gate.NAND: lambda a, b, c: 1 - (a & b), Gate.OR: lambda a, b, c: a | b, Gate.AND: lambda a, b, c: a & b,
-    Gate.XOR: lambda a, b, c: a ^ b, Gate.XNOR: lambda a, b, c: 1 - (a ^ b), Gate.NOR: lambda a, b, c: 1 - (a | b),
-    Gate.ANDNY: lambda a, b, c: (1 - a) & b, Gate.ANDYN: lambda a, b, c: a & (1 - b),
-    Gate.ORNY: lambda a, b, c: (1 - a) | b, Gate.ORYN: lambda a, b, c: a | (1 - b),
-    Gate.MUX: lambda a, b, c: np.where(a == 1, b, c), Gate.NOT: lambda a, b, c: 1 - a, Gate.COPY: lambda a, b, c: a,
-    Gate.CONST1: lambda a, b, c: np.ones_like(a), Gate.CONST0: lambda a, b, c: np.zeros_like(a),
-}
+from tests.truth import TRUTH  # noqa: E402
 
 
 @pytest.mark.parametrize("gate", list(Gate))
@@ -123,7 +116,7 @@ def test_every_gate_bit_exact_and_truth_table(gate, engine, oracle, okeys, clien
     ca, cb, cc = client.encrypt(keys, a, 31), client.encrypt(keys, b, 32), client.encrypt(keys, c, 33)
     got = engine.gate_batch(gate, ca, cb, cc)
     dec, phases = client.decrypt(keys, got)
-    assert np.array_equal(dec, TRUTH[gate](a.astype(np.int64), b.astype(np.int64), c.astype(np.int64)))
+    assert np.array_equal(dec, TRUTH[int(gate)](a.astype(np.int64), b.astype(np.int64), c.astype(np.int64)))
     ncheck = 8 if gate >= Gate.NOT else 2
     for i in range(ncheck):
         assert np.array_equal(got[i], oracle.gate(okeys, gate, ca[i], cb[i], cc[i])), i

@@ -1,0 +1,81 @@
+"""Multi-GPU host logic: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in CPU tests).  The reference has no parallel code at all; what shards here is what is
+independent in the reference: the gates of one batch / one netlist level.
+
+  * keys are generated once and REPLICATED: one broadcast of the coefficient-domain bootstrapping key (31 MB) and the
+    keyswitch key (83 MB) from rank 0; every rank converts to the FFT domain on its own GPU,
+  * gates shard in contiguous blocks, no collective on the data path,
+  * results are all-gathered only when the caller needs the whole array on every rank (next level of a netlist).
+"""
+import numpy as np
+
+from .client import KeySet
+from .engine import PARAMS as P
+
+
+def shard_bounds(count, rank, world):
+    """contiguous block [lo, hi) of `count` items owned by `rank`; sizes differ by at most one"""
+    base, rem = divmod(int(count), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def broadcast_keys(keys, device=None, src=0):
+    """rank `src` passes its KeySet, the others pass None; returns the KeySet on every rank"""
+    import torch
+    dist = _dist()
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return keys
+    shapes = {"lwe_key": (P.n,), "tlwe_key": (P.N,), "bk_coef": (P.n, P.kpl, 2, P.N),
+              "ks": (P.N, P.ks_t, P.ks_base, P.n + 1)}
+    dev = device if device is not None else torch.device("cpu")
+    seed = torch.tensor([keys.seed if dist.get_rank() == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(seed, src=src)
+    parts = {}
+    for name, shp in shapes.items():
+        if dist.get_rank() == src:
+            t = torch.from_numpy(np.ascontiguousarray(getattr(keys, name))).to(dev)
+        else:
+            t = torch.empty(shp, dtype=torch.int32, device=dev)
+        dist.broadcast(t, src=src)
+        parts[name] = t.cpu().numpy()
+    return KeySet(int(seed.item()), **parts)
+
+
+def all_gather_rows(local, count, device=None):
+    """local: int32 array [hi-lo, width] of this rank's shard (shard_bounds order) -> full [count, width] everywhere"""
+    import torch
+    dist = _dist()
+    local = np.ascontiguousarray(local, dtype=np.int32)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, width = dist.get_world_size(), local.shape[1]
+    dev = device if device is not None else torch.device("cpu")
+    cap = -(-int(count) // world)
+    buf = torch.zeros((cap, width), dtype=torch.int32, device=dev)
+    buf[:local.shape[0]] = torch.from_numpy(local).to(dev)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    out = np.empty((count, width), np.int32)
+    for r in range(world):
+        lo, hi = shard_bounds(count, r, world)
+        out[lo:hi] = parts[r][:hi - lo].cpu().numpy()
+    return out
+
+
+def sharded_gate_batch(gate_fn, gate, a, b=None, c=None, gather=True, device=None):
+    """evaluates one batch of independent gates over all ranks.  gate_fn(gate, a, b, c) -> outputs for the rows it is
+    given (Engine.gate_batch on the GPU box).  Every rank holds the full inputs; returns the full outputs (gather) or
+    the local shard."""
+    dist = _dist()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    count = a.shape[0]
+    lo, hi = shard_bounds(count, rank, world)
+    sl = slice(lo, hi)
+    local = gate_fn(gate, a[sl], None if b is None else b[sl], None if c is None else c[sl])
+    return all_gather_rows(local, count, device) if gather else local
