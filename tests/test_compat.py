@@ -1,0 +1,94 @@
+"""Struct-level libtfhe shim (include/tfhe_hip_compat.h): layout of the struct views and, on the GPU, the libtfhe-style
+bootsXXX_batch functions and the reference seam tfhe_hip_blindRotate_FFT driven through pointer-rich structs."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.oracle_lib import P, have_ref
+from tfhe_amd import PARAMS as PR
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "tests", "compat", "libcompat_harness.so")
+
+REF_LAYOUT_PROG = r'''
+#include <cstdio>
+#include <cstddef>
+#include "tfhe.h"
+int main() {
+    long long o[] = { sizeof(LweSample), offsetof(LweSample, b), offsetof(LweSample, current_variance),
+      sizeof(LweParams), sizeof(TLweParams), offsetof(TLweParams, extracted_lweparams),
+      sizeof(TGswParams), offsetof(TGswParams, tlwe_params), offsetof(TGswParams, offset),
+      sizeof(LweKeySwitchKey), offsetof(LweKeySwitchKey, ks),
+      sizeof(TLweSample), sizeof(TLweSampleFFT), sizeof(TGswSampleFFT),
+      sizeof(LweBootstrappingKeyFFT), offsetof(LweBootstrappingKeyFFT, bkFFT), offsetof(LweBootstrappingKeyFFT, ks),
+      sizeof(TFheGateBootstrappingParameterSet), sizeof(TFheGateBootstrappingCloudKeySet),
+      offsetof(TFheGateBootstrappingCloudKeySet, bkFFT), sizeof(LagrangeHalfCPolynomial), sizeof(TorusPolynomial) };
+    for (auto v : o) printf("%lld\n", v);
+}
+'''
+
+
+def harness_layout():
+    lib = ctypes.CDLL(HARNESS)
+    o = np.zeros(22, np.int64)
+    lib.harness_layout(P(o))
+    return o.tolist()
+
+
+def test_views_have_plausible_layout():
+    o = harness_layout()
+    assert o[0] == 24 and o[1] == 8 and o[2] == 16          # LweSample {ptr, int32, double}
+    assert o[20] == 8192 and o[21] == 4096                    # LagrangeHalfCPolynomial, TorusPolynomial
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not have_ref(), reason="reference headers absent")
+def test_views_match_reference_headers(tmp_path):
+    src = tmp_path / "layout.cpp"
+    src.write_text(REF_LAYOUT_PROG)
+    exe = str(tmp_path / "layout")
+    subprocess.run(["g++", "-std=c++11", "-w", "-Wno-invalid-offsetof", "-I/root/reference/src/include", str(src),
+                    "-o", exe], check=True)
+    ref = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    assert ref == harness_layout()
+
+
+@pytest.fixture(scope="module")
+def keyset(oracle, okeys, keys):
+    lib = ctypes.CDLL(HARNESS)
+    lib.harness_make_keyset.restype = ctypes.c_void_p
+    bkfft = np.ascontiguousarray(oracle.bkfft(okeys))
+    h = ctypes.c_void_p(lib.harness_make_keyset(P(bkfft), P(np.ascontiguousarray(keys.ks))))
+    yield lib, h
+    ctypes.CDLL(os.path.join(ROOT, "tfhe_amd", "libtfhe_hip.so")).tfhe_hip_default_context_reset()
+    lib.harness_free_keyset(h)
+
+
+@pytest.mark.gpu
+def test_boots_batch_functions_on_reference_structs(keyset, client, keys, oracle, okeys):
+    from tests.truth import TRUTH
+    lib, h = keyset
+    a = np.array([0, 1, 0, 1, 0, 1, 0, 1], np.uint8)
+    b = np.array([0, 0, 1, 1, 0, 0, 1, 1], np.uint8)
+    c = np.array([0, 0, 0, 0, 1, 1, 1, 1], np.uint8)
+    ca, cb, cc = client.encrypt(keys, a, 31), client.encrypt(keys, b, 32), client.encrypt(keys, c, 33)
+    for gate in range(15):
+        out = np.zeros((8, PR.n + 1), np.int32)
+        lib.harness_gate(h, gate, P(out), P(ca), P(cb), P(cc), 8)
+        dec, _ = client.decrypt(keys, out)
+        assert np.array_equal(dec, TRUTH[gate](a.astype(np.int64), b.astype(np.int64), c.astype(np.int64))), gate
+        assert np.array_equal(out[5], oracle.gate(okeys, gate, ca[5], cb[5], cc[5])), gate
+
+
+@pytest.mark.gpu
+def test_reference_seam_signature(keyset, oracle, okeys):
+    lib, h = keyset
+    rng = np.random.default_rng(8)
+    acc = rng.integers(-2**31, 2**31, (2, PR.N)).astype(np.int32)
+    bara = rng.integers(0, 2 * PR.N, PR.n).astype(np.int32)
+    want = oracle.blind_rotate(okeys, acc, bara)
+    lib.harness_blind_rotate(h, P(acc), P(bara))
+    assert np.array_equal(acc, want)

@@ -60,10 +60,21 @@ def build_oracle(force=False):
              stderr=subprocess.DEVNULL)
 
 
+def build_test_harness(force=False):
+    """tests/compat/libcompat_harness.so: a stand-in application written against libtfhe's structs (test only)"""
+    out = os.path.join(ROOT, "tests", "compat", "libcompat_harness.so")
+    src = os.path.join(ROOT, "tests", "compat", "compat_harness.cpp")
+    if force or _stale(out, [src, os.path.join(ROOT, "include", "tfhe_hip_compat.h")]):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-o", out, src,
+              "-L" + os.path.join(ROOT, "tfhe_amd"), "-ltfhe_hip", "-Wl,-rpath,$ORIGIN/../../tfhe_amd"])
+    return out
+
+
 def build_all(force=False):
     build_hip(force)
     build_client(force)
     build_oracle(force)
+    build_test_harness(force)
 
 
 if __name__ == "__main__":

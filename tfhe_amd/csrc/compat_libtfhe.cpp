@@ -1,0 +1,164 @@
+// Struct-level libtfhe shim (include/tfhe_hip_compat.h): flattens the reference's pointer-rich structs, calls the
+// batched C-ABI, scatters results back.  Host code only; no kernels here.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+#include "../../include/tfhe_hip_compat.h"
+
+namespace {
+constexpr int kn = TFHE_HIP_n, kN = TFHE_HIP_N, kKpl = TFHE_HIP_KPL, kT = TFHE_HIP_KS_T, kBase = TFHE_HIP_KS_BASE;
+
+std::mutex g_mu;
+tfhe_hip_ctx *g_ctx = nullptr;
+const void *g_loaded_keyset = nullptr;   // TFheGateBootstrappingCloudKeySet* or TGswSampleFFT* currently uploaded
+
+[[noreturn]] void die(const char *what) {
+    std::fprintf(stderr, "tfhe_hip: %s: %s\n", what, tfhe_hip_last_error());
+    std::abort();
+}
+
+void flatten_bkfft(std::vector<double> &dst, const TGswSampleFFT *bk) {
+    dst.resize((size_t) kn * kKpl * 2 * kN);
+    for (int i = 0; i < kn; i++)
+        for (int p = 0; p < kKpl; p++)
+            for (int c = 0; c < 2; c++)
+                std::memcpy(dst.data() + (((size_t) i * kKpl + p) * 2 + c) * kN, bk[i].all_samples[p].a[c].coefsC,
+                            sizeof(double) * kN);
+}
+
+int load_keys(tfhe_hip_ctx *ctx, const TGswSampleFFT *bk, const LweKeySwitchKey *ks) {
+    std::vector<double> fbk;
+    flatten_bkfft(fbk, bk);
+    std::vector<int32_t> fks((size_t) kN * kT * kBase * (kn + 1), 0);
+    if (ks) {
+        if (ks->n != kN || ks->t != kT || ks->base != kBase) return TFHE_HIP_ERR_ARG;
+        for (int i = 0; i < kN; i++)
+            for (int j = 0; j < kT; j++)
+                for (int d = 0; d < kBase; d++) {
+                    const LweSample *s = &ks->ks[i][j][d];
+                    int32_t *row = fks.data() + (((size_t) i * kT + j) * kBase + d) * (kn + 1);
+                    std::memcpy(row, s->a, sizeof(int32_t) * kn);
+                    row[kn] = s->b;
+                }
+    }
+    return tfhe_hip_load_keys_fft(ctx, fbk.data(), fks.data());
+}
+
+tfhe_hip_ctx *default_ctx_locked() {
+    if (!g_ctx) {
+        const char *d = std::getenv("TFHE_HIP_DEVICE");
+        if (tfhe_hip_create(&g_ctx, d ? std::atoi(d) : 0) != 0) die("creating the default context");
+    }
+    return g_ctx;
+}
+
+void pack(std::vector<int32_t> &dst, const LweSample *s, int32_t count) {
+    dst.resize((size_t) count * (kn + 1));
+    for (int32_t i = 0; i < count; i++) {
+        std::memcpy(dst.data() + (size_t) i * (kn + 1), s[i].a, sizeof(int32_t) * kn);
+        dst[(size_t) i * (kn + 1) + kn] = s[i].b;
+    }
+}
+
+void boots_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b, const LweSample *c, int32_t count,
+                 const TFheGateBootstrappingCloudKeySet *bk) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    tfhe_hip_ctx *ctx = default_ctx_locked();
+    if (gate <= TFHE_HIP_MUX && g_loaded_keyset != (const void *) bk) {
+        if (!bk || tfhe_hip_load_cloud_keyset(ctx, bk) != 0) die("uploading the cloud keyset");
+        g_loaded_keyset = bk;
+    }
+    if (tfhe_hip_gate_batch_samples(ctx, gate, result, a, b, c, count) != 0) die("gate batch");
+}
+}  // namespace
+
+extern "C" {
+
+int tfhe_hip_load_cloud_keyset(tfhe_hip_ctx *ctx, const TFheGateBootstrappingCloudKeySet *keyset) {
+    if (!ctx || !keyset || !keyset->bkFFT || !keyset->bkFFT->bkFFT || !keyset->bkFFT->ks) return TFHE_HIP_ERR_ARG;
+    const LweBootstrappingKeyFFT *k = keyset->bkFFT;
+    if (k->in_out_params->n != kn || k->accum_params->N != kN || k->accum_params->k != 1 || k->bk_params->l != 3 ||
+        k->bk_params->Bgbit != 7)
+        return TFHE_HIP_ERR_ARG;   // only the default parameter set (reference tfhe_core.h:13-24 is constexpr too)
+    return load_keys(ctx, k->bkFFT, k->ks);
+}
+
+int tfhe_hip_gate_batch_samples(tfhe_hip_ctx *ctx, int gate, LweSample *result, const LweSample *a,
+                                const LweSample *b, const LweSample *c, int32_t count) {
+    if (!ctx || count < 0 || (count > 0 && !result)) return TFHE_HIP_ERR_ARG;
+    if (count == 0) return TFHE_HIP_OK;
+    std::vector<int32_t> fa, fb, fc, fo((size_t) count * (kn + 1));
+    if (a) pack(fa, a, count);
+    if (b) pack(fb, b, count);
+    if (c) pack(fc, c, count);
+    int rc = tfhe_hip_gate_batch(ctx, gate, fo.data(), a ? fa.data() : nullptr, b ? fb.data() : nullptr,
+                                 c ? fc.data() : nullptr, count);
+    if (rc != 0) return rc;
+    for (int32_t i = 0; i < count; i++) {
+        std::memcpy(result[i].a, fo.data() + (size_t) i * (kn + 1), sizeof(int32_t) * kn);
+        result[i].b = fo[(size_t) i * (kn + 1) + kn];
+        result[i].current_variance = 0.;   // bookkeeping only in the reference (SURVEY 8(a) note 2)
+    }
+    return TFHE_HIP_OK;
+}
+
+#define BINARY(NAME, ID)                                                                                      \
+    void NAME(LweSample *r, const LweSample *ca, const LweSample *cb, int32_t count,                          \
+              const TFheGateBootstrappingCloudKeySet *bk) {                                                   \
+        boots_batch(ID, r, ca, cb, nullptr, count, bk);                                                       \
+    }
+BINARY(bootsNAND_batch, TFHE_HIP_NAND)
+BINARY(bootsOR_batch, TFHE_HIP_OR)
+BINARY(bootsAND_batch, TFHE_HIP_AND)
+BINARY(bootsXOR_batch, TFHE_HIP_XOR)
+BINARY(bootsXNOR_batch, TFHE_HIP_XNOR)
+BINARY(bootsNOR_batch, TFHE_HIP_NOR)
+BINARY(bootsANDNY_batch, TFHE_HIP_ANDNY)
+BINARY(bootsANDYN_batch, TFHE_HIP_ANDYN)
+BINARY(bootsORNY_batch, TFHE_HIP_ORNY)
+BINARY(bootsORYN_batch, TFHE_HIP_ORYN)
+#undef BINARY
+
+void bootsMUX_batch(LweSample *r, const LweSample *a, const LweSample *b, const LweSample *c, int32_t count,
+                    const TFheGateBootstrappingCloudKeySet *bk) {
+    boots_batch(TFHE_HIP_MUX, r, a, b, c, count, bk);
+}
+void bootsNOT_batch(LweSample *r, const LweSample *ca, int32_t count, const TFheGateBootstrappingCloudKeySet *bk) {
+    boots_batch(TFHE_HIP_NOT, r, ca, nullptr, nullptr, count, bk);
+}
+void bootsCOPY_batch(LweSample *r, const LweSample *ca, int32_t count, const TFheGateBootstrappingCloudKeySet *bk) {
+    boots_batch(TFHE_HIP_COPY, r, ca, nullptr, nullptr, count, bk);
+}
+void bootsCONSTANT_batch(LweSample *r, int32_t value, int32_t count, const TFheGateBootstrappingCloudKeySet *bk) {
+    boots_batch(value ? TFHE_HIP_CONST1 : TFHE_HIP_CONST0, r, nullptr, nullptr, nullptr, count, bk);
+}
+
+void tfhe_hip_blindRotate_FFT(TLweSample *accum, const TGswSampleFFT *bk, const int32_t *bara, const int32_t n,
+                              const TGswParams *bk_params) {
+    (void) bk_params;
+    std::lock_guard<std::mutex> lock(g_mu);
+    tfhe_hip_ctx *ctx = default_ctx_locked();
+    if (n != kn || !accum || !bk || !bara) {
+        std::fprintf(stderr, "tfhe_hip_blindRotate_FFT: bad arguments\n");
+        std::abort();
+    }
+    if (g_loaded_keyset != (const void *) bk) {
+        if (load_keys(ctx, bk, nullptr) != 0) die("uploading the bootstrapping key");
+        g_loaded_keyset = bk;
+    }
+    std::vector<int32_t> acc(2 * kN);
+    for (int c = 0; c < 2; c++) std::memcpy(acc.data() + c * kN, accum->a[c].coefsT, sizeof(int32_t) * kN);
+    if (tfhe_hip_blind_rotate_batch(ctx, acc.data(), bara, 1) != 0) die("blind rotation");
+    for (int c = 0; c < 2; c++) std::memcpy(accum->a[c].coefsT, acc.data() + c * kN, sizeof(int32_t) * kN);
+}
+
+void tfhe_hip_default_context_reset(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g_ctx) tfhe_hip_destroy(g_ctx);
+    g_ctx = nullptr;
+    g_loaded_keyset = nullptr;
+}
+
+}  // extern "C"
