@@ -345,6 +345,130 @@ __global__ __launch_bounds__(192) void k_keyswitch(const int32_t *__restrict__ i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// keyswitch on the matrix cores.  The gather-subtract above is a product of a one-hot digit matrix with the key:
+//     sum_{i,j} ks[i][j][d_gij][q]  =  sum_k A[g][k] * K[k][q],   k = (i, j, d),  A[g][(i,j,d)] = [d_gij == d]
+// (the d = 0 column meets an all-zero key row).  K is split into four signed byte limbs, K = sum_l s_l 256^l with
+// s_l in [-128,127], so each limb product is an exact int8 x int8 -> int32 MFMA (|sum| <= 8192*128 < 2^31) and
+// out = (0,b') - sum_l (A s_l) << 8l  (mod 2^32) is the reference's result bit for bit.
+// v_mfma_i32_32x32x32_i8: M = 32 ciphertexts, N = 32 output coefficients, K = 32 = one input coefficient i
+// (8 digits j x 4 digit values d).  A fragments are built in registers from the transposed input; B fragments are
+// 16-byte loads from the key stored as int8[i][limb][q][j][d].
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kKsQ = 640;     // output coefficients padded to 20 tiles of 32
+constexpr int kKsMT = 4;      // 32-ciphertext tiles per wave
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+// [N][t][4][n+1] int32 -> [N][4 limbs][640][t][4] int8
+__global__ void k_ks_pack_mfma(int8_t *__restrict__ dst, const int32_t *__restrict__ src) {
+    const int i = blockIdx.x;
+    for (int q = threadIdx.x; q < kKsQ; q += blockDim.x) {
+        uint32_t limb[4][8];  // [limb][j] packs 4 bytes (d = 0..3)
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) limb[l][j] = 0;
+        if (q < kCt) {
+#pragma unroll
+            for (int j = 0; j < kKsT; j++)
+#pragma unroll
+                for (int d = 1; d < 4; d++) {
+                    uint32_t v = (uint32_t) src[(((size_t) i * kKsT + j) * 4 + d) * kCt + q];
+#pragma unroll
+                    for (int l = 0; l < 4; l++) {
+                        const int32_t sb = (int32_t) (int8_t) (v & 0xffu);  // signed low byte
+                        limb[l][j] |= ((uint32_t) sb & 0xffu) << (8 * d);
+                        v = (v - (uint32_t) sb) >> 8;                        // exact: low byte is now zero
+                    }
+                }
+        }
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            uint32_t *o = reinterpret_cast<uint32_t *>(dst + (((size_t) i * 4 + l) * kKsQ + q) * 32);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = limb[l][j];
+        }
+    }
+}
+
+// in[B][N+1] -> abarT[N][Bp] = a_i + 2^15 (lwe-keyswitch-functions.cpp:119,123); padding ciphertexts get digit 0
+__global__ void k_ks_transpose(uint32_t *__restrict__ abarT, const int32_t *__restrict__ in, long long B, long long Bp) {
+    __shared__ uint32_t tile[32][33];
+    const long long g0 = (long long) blockIdx.x * 32;
+    const int i0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const uint32_t prec_offset = 1u << (32 - (1 + kKsBasebit * kKsT));
+    for (int r = ty; r < 32; r += 8) {
+        const long long g = g0 + r;
+        tile[r][tx] = g < B ? (uint32_t) in[g * kExt + i0 + tx] + prec_offset : 0u;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) abarT[(size_t) (i0 + r) * Bp + g0 + tx] = tile[tx][r];
+}
+
+// grid (Bp/128, 5), block 256: wave w of block (x, y) owns ciphertexts [128x, 128x+128) and coefficients
+// [32(4y+w), 32(4y+w)+32)
+__global__ __launch_bounds__(256) void k_keyswitch_mfma(const uint32_t *__restrict__ abarT, const int8_t *__restrict__ kl,
+                                                        const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                        long long B, long long Bp) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r32 = lane & 31, h = lane >> 5;
+    const long long g0 = (long long) blockIdx.x * (32 * kKsMT);
+    const int q = (blockIdx.y * 4 + wave) * 32 + r32;
+    const uint32_t *ap = abarT + g0 + r32;
+    const v4i_t *bp = reinterpret_cast<const v4i_t *>(kl) + (size_t) q * 2 + h;
+    uint32_t total[kKsMT][16];
+#pragma unroll
+    for (int m = 0; m < kKsMT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) total[m][r] = 0;
+#pragma unroll 1
+    for (int lp = 0; lp < 2; lp++) {  // two limbs per pass
+        v16i_t acc[2][kKsMT];
+#pragma unroll
+        for (int l = 0; l < 2; l++)
+#pragma unroll
+            for (int m = 0; m < kKsMT; m++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[l][m][r] = 0;
+#pragma unroll 2
+        for (int i = 0; i < kN; i++) {
+            const v4i_t b0 = bp[((size_t) i * 4 + 2 * lp) * kKsQ * 2];
+            const v4i_t b1 = bp[((size_t) i * 4 + 2 * lp + 1) * kKsQ * 2];
+#pragma unroll
+            for (int m = 0; m < kKsMT; m++) {
+                const uint32_t ab = ap[(size_t) i * Bp + 32 * m];
+                v4i_t a;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    // digit j = 4h + jj: ((ab >> (30 - 2j)) & 3); one-hot byte position = digit
+                    const uint32_t sh = (ab >> (27 - 2 * jj - 8 * h)) & 24u;
+                    a[jj] = (int) (1u << sh);
+                }
+                acc[0][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc[0][m], 0, 0, 0);
+                acc[1][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc[1][m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < kKsMT; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                total[m][r] += ((uint32_t) acc[0][m][r] << (16 * lp)) + ((uint32_t) acc[1][m][r] << (16 * lp + 8));
+    }
+    if (q > kLwe) return;
+#pragma unroll
+    for (int m = 0; m < kKsMT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long long g = g0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (g < B) {
+                const uint32_t init = q == kLwe ? (uint32_t) in[g * kExt + kN] : 0u;
+                out[g * kCt + q] = (int32_t) (init - total[m][r]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // small element-wise kernels of the gate layer
 // ---------------------------------------------------------------------------------------------------------------
 // bootsMUX tail (boot-gates.cpp:357-361): u1 <- (0,MU) + u1 + u2 on LWE_N samples
@@ -579,9 +703,11 @@ struct tfhe_hip_ctx {
     c64 *tw = nullptr;
     PhaseAConsts ka{};
     c64 *bk = nullptr;       // [n][6][2][512] physical order
-    int32_t *ks = nullptr;   // [N][t][3][632]
+    int32_t *ks = nullptr;   // [N][t][3][632]   (VALU keyswitch, kept for the ragged tail / A-B checks)
+    int8_t *kl = nullptr;    // [N][4][640][t][4] byte limbs (MFMA keyswitch)
+    int ks_mfma = 1;
     bool have_keys = false;
-    DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc;
+    DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc, abart;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // br start/stop, ks start/stop
     bool ev_br = false, ev_ks = false;
     int br_waves = 8;
@@ -615,8 +741,17 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A) {
 
 int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B) {
     if (B <= 0) return TFHE_HIP_OK;
-    dim3 grid((unsigned) ((B + kKsG - 1) / kKsG));
-    hipLaunchKernelGGL(k_keyswitch, grid, dim3(192), 0, c->stream, d_in, c->ks, d_out, B);
+    if (c->ks_mfma) {
+        const long long Bp = (B + 127) / 128 * 128;
+        HIPCHK(c->abart.reserve((size_t) kN * Bp * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_ks_transpose, dim3((unsigned) (Bp / 32), kN / 32), dim3(256), 0, c->stream,
+                           (uint32_t *) c->abart.p, d_in, B, Bp);
+        hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) (Bp / 128), 5), dim3(256), 0, c->stream,
+                           (const uint32_t *) c->abart.p, (const int8_t *) c->kl, d_in, d_out, B, Bp);
+    } else {
+        dim3 grid((unsigned) ((B + kKsG - 1) / kKsG));
+        hipLaunchKernelGGL(k_keyswitch, grid, dim3(192), 0, c->stream, d_in, c->ks, d_out, B);
+    }
     HIPCHK(hipGetLastError());
     return TFHE_HIP_OK;
 }
@@ -656,6 +791,9 @@ int upload_ks(tfhe_hip_ctx *c, const int32_t *ks) {
     const long long rows = (long long) kN * kKsT * 3;
     hipLaunchKernelGGL(k_ks_pack, dim3((unsigned) rows), dim3(256), 0, c->stream, c->ks, (const int32_t *) c->misc.p, rows);
     HIPCHK(hipGetLastError());
+    if (!c->kl) HIPCHK(hipMalloc((void **) &c->kl, (size_t) kN * 4 * kKsQ * 32));
+    hipLaunchKernelGGL(k_ks_pack_mfma, dim3(kN), dim3(128), 0, c->stream, c->kl, (const int32_t *) c->misc.p);
+    HIPCHK(hipGetLastError());
     return TFHE_HIP_OK;
 }
 
@@ -681,6 +819,8 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     const char *w = getenv("TFHE_HIP_BR_WAVES");
     if (w && atoi(w) == 8) c->br_waves = 8;
     if (w && atoi(w) == 4) c->br_waves = 4;
+    const char *km = getenv("TFHE_HIP_KS_MFMA");
+    if (km) c->ks_mfma = atoi(km) != 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **) &c->tw, kTwEntries * sizeof(c64));
     if (e == hipSuccess) e = hipMemcpy(c->tw, tw.data(), kTwEntries * sizeof(c64), hipMemcpyHostToDevice);
@@ -697,10 +837,11 @@ void tfhe_hip_destroy(tfhe_hip_ctx *c) {
     if (!c) return;
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->in_a, &c->in_b, &c->in_c, &c->ext1, &c->ext2, &c->outb, &c->misc}) b->release();
+    for (DevBuf *b : {&c->in_a, &c->in_b, &c->in_c, &c->ext1, &c->ext2, &c->outb, &c->misc, &c->abart}) b->release();
     if (c->tw) (void) hipFree(c->tw);
     if (c->bk) (void) hipFree(c->bk);
     if (c->ks) (void) hipFree(c->ks);
+    if (c->kl) (void) hipFree(c->kl);
     for (int i = 0; i < 4; i++)
         if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
     if (c->stream) (void) hipStreamDestroy(c->stream);
