@@ -38,7 +38,7 @@ def cpu_baseline(keys, ca, cb, expect_bits, client):
     from tests.oracle_lib import Oracle, REF_SO, P
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     threads = max(1, min(threads, 64))
-    per_thread = 4
+    per_thread = 12
     count = threads * per_thread
     a, b = np.ascontiguousarray(ca[:count]), np.ascontiguousarray(cb[:count])
     out = np.zeros_like(a)

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtfhe_hip.so")
+LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(_HERE, "libtfhe_hip.so")  # override: A/B builds
 
 
 class PARAMS:
