@@ -67,6 +67,50 @@ def cpu_baseline(keys, ca, cb, expect_bits, client):
                       % (count, per_thread, threads, dt, 1e3 * dt * threads / count)}, out
 
 
+def side_bench(args, torch, dev, rank, world):
+    """BASELINE configs[4]: bootsMUX batch (two bootstraps + one keyswitch per gate) and the batched negacyclic
+    IntPolynomial x TorusPolynomial FFT product at N = 1024 (torusPolynomialMultFFT, reference polynomials.cpp:241).
+    N = 2048 is not offered: the reference's transform is compiled for N = 1024 only (tfhe_core.h:14)."""
+    from tfhe_amd import Client, Engine, Gate, PARAMS as PR
+    assert world == 1, "side benches are single-GPU"
+    eng = Engine(0)
+    if args.workload == "mux":
+        client = Client()
+        keys = client.keygen(42)
+        eng.load_keys_coef(keys.bk_coef, keys.ks)
+        B = args.batch
+        rng = np.random.default_rng(5)
+        bits = [rng.integers(0, 2, B).astype(np.uint8) for _ in range(3)]
+        d = [torch.from_numpy(client.encrypt(keys, b, seed=50 + i)).to(dev) for i, b in enumerate(bits)]
+        d_out = torch.empty((B, PR.n + 1), dtype=torch.int32, device=dev)
+        run = lambda: eng.gate_batch_dev(Gate.MUX, d_out, d[0], d[1], d[2], count=B)  # noqa: E731
+        unit, per_step, name = "gates/s", B, "bootsMUX gates/sec (2 bootstraps + 1 keyswitch each)"
+    else:
+        B = 1 << 16
+        rng = np.random.default_rng(6)
+        a = torch.from_numpy(rng.integers(-2 * PR.N, 2 * PR.N, (B, PR.N)).astype(np.int32)).to(dev)
+        b = torch.from_numpy(rng.integers(-2**31, 2**31, (B, PR.N)).astype(np.int32)).to(dev)
+        d_out = torch.empty((B, PR.N), dtype=torch.int32, device=dev)
+        run = lambda: eng.negacyclic_mul_dev(d_out, a, b, B)  # noqa: E731
+        unit, per_step, name = "products/s", B, "negacyclic IntPolynomial x TorusPolynomial FFT products/sec, N=1024"
+    for _ in range(args.warmup):
+        run()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    eng.sync()
+    dt = time.perf_counter() - t0
+    if args.workload == "mux":
+        dec, _ = client.decrypt(keys, d_out.cpu().numpy())
+        assert np.array_equal(dec, np.where(bits[0] == 1, bits[1], bits[2])), "MUX outputs decrypt wrongly"
+    print(json.dumps({"metric": name, "value": per_step * args.steps / dt, "unit": unit, "n_gpus": 1,
+                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                      "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": args.workload, "batch": per_step}}), flush=True)
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +118,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=16384, help="gates per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="nand", choices=["nand", "mux", "fft"],
+                    help="nand: BASELINE configs[1] (default, the headline); mux / fft: BASELINE configs[4] side benches")
     args = ap.parse_args()
 
     import torch
@@ -89,6 +135,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload != "nand":
+        return side_bench(args, torch, dev, rank, world)
 
     client = Client()
     # ---- keys: generated once (rank 0), replicated to every GPU by an RCCL broadcast -------------------------

@@ -112,6 +112,21 @@ void *tfhe_hip_stream(tfhe_hip_ctx *ctx);
  * (blind rotation incl. pre-combination and extraction; keyswitch).  Synchronises the stream. */
 int tfhe_hip_last_kernel_ms(tfhe_hip_ctx *ctx, float *blind_rotate_ms, float *keyswitch_ms);
 
+/* ---- one level of a netlist on a device-resident ciphertext pool ----------------------------
+ * The reference evaluates circuits as sequential loops of bootsXXX calls (src/test/test-addition-boot.cpp:30-115);
+ * here all gates of one dependency level run as one batch, inputs gathered from and outputs scattered to rows of
+ * d_pool (int32[pool_rows][n+1] in device memory).
+ * gates: HOST array int32[count][5] = {gate id, out row, a row, b row, c row}; unused operands are ignored.
+ * A level reads the pool as it was before the call: a row may not be written twice, nor read and written, within
+ * one call (rejected with TFHE_HIP_ERR_ARG before anything is launched).  Returns after the level has completed. */
+int tfhe_hip_gate_level_dev(tfhe_hip_ctx *ctx, int32_t *d_pool, int64_t pool_rows, const int32_t *gates,
+                            int64_t count);
+/* device-memory helpers, so that C callers of the *_dev entry points need no HIP of their own */
+int tfhe_hip_dev_alloc(tfhe_hip_ctx *ctx, size_t bytes, void **out);
+int tfhe_hip_dev_free(tfhe_hip_ctx *ctx, void *ptr);
+int tfhe_hip_copy_to_dev(tfhe_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int tfhe_hip_copy_from_dev(tfhe_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
+
 /* ---- stage-level entry points (host buffers), for parity tests and the FFT microbench ----------------------- */
 /* tfhe_blindRotate_FFT (the reference seam itself): acc[count][2][N] in/out, bara[count][n] in [0,2N) */
 int tfhe_hip_blind_rotate_batch(tfhe_hip_ctx *ctx, int32_t *acc, const int32_t *bara, int64_t count);

@@ -132,7 +132,17 @@ __device__ __forceinline__ void load_tw_to_lds(c64 *tw_lds, const c64 *tw) {
 // ---------------------------------------------------------------------------------------------------------------
 // blind rotation
 // ---------------------------------------------------------------------------------------------------------------
+// one bootstrap of a netlist level: tmp = (0,cst) + sa*pool[ia] + sb*pool[ib]  (ib < 0: no second operand)
+struct BrJob {
+    int32_t ia, ib, sa, sb, cst, pad0, pad1, pad2;
+};
+// one keyswitch of a netlist level: pool[out] = KS(ext[e1] (+ ext[e2]) + (0,bconst))  (e2 < 0: single operand)
+struct KsJob {
+    int32_t e1, e2, bconst, out;
+};
+
 struct BrArgs {
+    const BrJob *jobs;     // MODE_GATE, optional: per-wave job list over a ciphertext pool at `a`
     const int32_t *a, *b;  // MODE_GATE: LWE_n inputs [B][n+1] (b may be null)
     int32_t sa, sb, cst;   //            tmp = (0,cst) + sa*a + sb*b          (boot-gates.cpp)
     int32_t mu;            //            test vector constant
@@ -235,12 +245,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
         // pre-combination folded in; tfhe_blindRotateAndExtract_FFT (:180-209)
         const int32_t *ga = A.a + g * kCt;
         const int32_t *gb = A.b ? A.b + g * kCt : nullptr;
+        int32_t sa = A.sa, sb = A.sb, cst = A.cst;
+        if (A.jobs) {  // netlist level: operands are rows of the pool, coefficients per job
+            const BrJob *j = A.jobs + g;
+            const int ia = __builtin_amdgcn_readfirstlane(j->ia), ib = __builtin_amdgcn_readfirstlane(j->ib);
+            sa = __builtin_amdgcn_readfirstlane(j->sa);
+            sb = __builtin_amdgcn_readfirstlane(j->sb);
+            cst = __builtin_amdgcn_readfirstlane(j->cst);
+            ga = A.a + (long long) ia * kCt;
+            gb = ib >= 0 ? A.a + (long long) ib * kCt : nullptr;
+        }
         auto comb = [&](int i) -> int32_t {
-            uint32_t t = (uint32_t) A.sa * (uint32_t) ga[i];
-            if (gb) t += (uint32_t) A.sb * (uint32_t) gb[i];
+            uint32_t t = (uint32_t) sa * (uint32_t) ga[i];
+            if (gb) t += (uint32_t) sb * (uint32_t) gb[i];
             return (int32_t) t;
         };
-        const int barb = modswitch_2N((int32_t) ((uint32_t) comb(kLwe) + (uint32_t) A.cst));
+        const int barb = modswitch_2N((int32_t) ((uint32_t) comb(kLwe) + (uint32_t) cst));
         // ACC = (0, X^(2N-barb) * [mu,...,mu])   (torusPolynomialMulByXai, toruspolynomial-functions.cpp:128-147)
 #pragma unroll
         for (int q = 0; q < 16; q++) {
@@ -392,7 +412,8 @@ __global__ void k_ks_pack_mfma(int8_t *__restrict__ dst, const int32_t *__restri
 }
 
 // in[B][N+1] -> abarT[N][Bp] = a_i + 2^15 (lwe-keyswitch-functions.cpp:119,123); padding ciphertexts get digit 0
-__global__ void k_ks_transpose(uint32_t *__restrict__ abarT, const int32_t *__restrict__ in, long long B, long long Bp) {
+__global__ void k_ks_transpose(uint32_t *__restrict__ abarT, const int32_t *__restrict__ in, long long B, long long Bp,
+                               const KsJob *__restrict__ kj) {
     __shared__ uint32_t tile[32][33];
     const long long g0 = (long long) blockIdx.x * 32;
     const int i0 = blockIdx.y * 32;
@@ -400,7 +421,18 @@ __global__ void k_ks_transpose(uint32_t *__restrict__ abarT, const int32_t *__re
     const uint32_t prec_offset = 1u << (32 - (1 + kKsBasebit * kKsT));
     for (int r = ty; r < 32; r += 8) {
         const long long g = g0 + r;
-        tile[r][tx] = g < B ? (uint32_t) in[g * kExt + i0 + tx] + prec_offset : 0u;
+        uint32_t v = 0u;
+        if (g < B) {
+            if (kj) {  // netlist level: sum of one or two extracted samples (bootsMUX, boot-gates.cpp:357-361)
+                const KsJob j = kj[g];
+                v = (uint32_t) in[(long long) j.e1 * kExt + i0 + tx];
+                if (j.e2 >= 0) v += (uint32_t) in[(long long) j.e2 * kExt + i0 + tx];
+            } else {
+                v = (uint32_t) in[g * kExt + i0 + tx];
+            }
+            v += prec_offset;
+        }
+        tile[r][tx] = v;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) abarT[(size_t) (i0 + r) * Bp + g0 + tx] = tile[tx][r];
@@ -410,7 +442,7 @@ __global__ void k_ks_transpose(uint32_t *__restrict__ abarT, const int32_t *__re
 // [32(4y+w), 32(4y+w)+32)
 __global__ __launch_bounds__(256) void k_keyswitch_mfma(const uint32_t *__restrict__ abarT, const int8_t *__restrict__ kl,
                                                         const int32_t *__restrict__ in, int32_t *__restrict__ out,
-                                                        long long B, long long Bp) {
+                                                        long long B, long long Bp, const KsJob *__restrict__ kj) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r32 = lane & 31, h = lane >> 5;
     const long long g0 = (long long) blockIdx.x * (32 * kKsMT);
@@ -462,8 +494,19 @@ __global__ __launch_bounds__(256) void k_keyswitch_mfma(const uint32_t *__restri
         for (int r = 0; r < 16; r++) {
             const long long g = g0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (g < B) {
-                const uint32_t init = q == kLwe ? (uint32_t) in[g * kExt + kN] : 0u;
-                out[g * kCt + q] = (int32_t) (init - total[m][r]);
+                uint32_t init = 0u;
+                long long orow = g;
+                if (kj) {
+                    const KsJob j = kj[g];
+                    orow = j.out;
+                    if (q == kLwe) {
+                        init = (uint32_t) in[(long long) j.e1 * kExt + kN] + (uint32_t) j.bconst;
+                        if (j.e2 >= 0) init += (uint32_t) in[(long long) j.e2 * kExt + kN];
+                    }
+                } else if (q == kLwe) {
+                    init = (uint32_t) in[g * kExt + kN];
+                }
+                out[orow * kCt + q] = (int32_t) (init - total[m][r]);
             }
         }
 }
@@ -488,6 +531,20 @@ __global__ void k_linear_gate(int32_t *out, const int32_t *a, int gate, int32_t 
     else if (gate == TFHE_HIP_COPY) v = a[i];
     else v = (i % kCt == kLwe) ? (gate == TFHE_HIP_CONST1 ? mu : (int32_t) (0u - (uint32_t) mu)) : 0;
     out[i] = v;
+}
+
+// netlist level: NOT / COPY / CONSTANT on pool rows; desc = {gate, out, a}
+__global__ void k_linear_level(int32_t *pool, const int32_t *desc, int32_t mu, long long count) {
+    const long long g = blockIdx.x;
+    if (g >= count) return;
+    const int gate = desc[3 * g], o = desc[3 * g + 1], a = desc[3 * g + 2];
+    for (int q = threadIdx.x; q < kCt; q += blockDim.x) {
+        int32_t v;
+        if (gate == TFHE_HIP_NOT) v = (int32_t) (0u - (uint32_t) pool[(long long) a * kCt + q]);
+        else if (gate == TFHE_HIP_COPY) v = pool[(long long) a * kCt + q];
+        else v = q == kLwe ? (gate == TFHE_HIP_CONST1 ? mu : (int32_t) (0u - (uint32_t) mu)) : 0;
+        pool[(long long) o * kCt + q] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -707,7 +764,11 @@ struct tfhe_hip_ctx {
     int8_t *kl = nullptr;    // [N][4][640][t][4] byte limbs (MFMA keyswitch)
     int ks_mfma = 1;
     bool have_keys = false;
-    DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc, abart;
+    DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc, abart, jobs_br, jobs_ks, jobs_lin;
+    std::vector<BrJob> h_br;
+    std::vector<KsJob> h_ks;
+    std::vector<int32_t> h_lin;
+    std::vector<uint8_t> h_mark;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // br start/stop, ks start/stop
     bool ev_br = false, ev_ks = false;
     int br_waves = 8;
@@ -739,15 +800,15 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A) {
     return TFHE_HIP_OK;
 }
 
-int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B) {
+int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B, const KsJob *kj = nullptr) {
     if (B <= 0) return TFHE_HIP_OK;
-    if (c->ks_mfma) {
+    if (c->ks_mfma || kj) {
         const long long Bp = (B + 127) / 128 * 128;
         HIPCHK(c->abart.reserve((size_t) kN * Bp * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_ks_transpose, dim3((unsigned) (Bp / 32), kN / 32), dim3(256), 0, c->stream,
-                           (uint32_t *) c->abart.p, d_in, B, Bp);
+                           (uint32_t *) c->abart.p, d_in, B, Bp, kj);
         hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) (Bp / 128), 5), dim3(256), 0, c->stream,
-                           (const uint32_t *) c->abart.p, (const int8_t *) c->kl, d_in, d_out, B, Bp);
+                           (const uint32_t *) c->abart.p, (const int8_t *) c->kl, d_in, d_out, B, Bp, kj);
     } else {
         dim3 grid((unsigned) ((B + kKsG - 1) / kKsG));
         hipLaunchKernelGGL(k_keyswitch, grid, dim3(192), 0, c->stream, d_in, c->ks, d_out, B);
@@ -837,7 +898,8 @@ void tfhe_hip_destroy(tfhe_hip_ctx *c) {
     if (!c) return;
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->in_a, &c->in_b, &c->in_c, &c->ext1, &c->ext2, &c->outb, &c->misc, &c->abart}) b->release();
+    for (DevBuf *b : {&c->in_a, &c->in_b, &c->in_c, &c->ext1, &c->ext2, &c->outb, &c->misc, &c->abart, &c->jobs_br, &c->jobs_ks,
+                      &c->jobs_lin}) b->release();
     if (c->tw) (void) hipFree(c->tw);
     if (c->bk) (void) hipFree(c->bk);
     if (c->ks) (void) hipFree(c->ks);
@@ -1143,6 +1205,104 @@ int tfhe_hip_negacyclic_mul_batch(tfhe_hip_ctx *c, int32_t *out, const int32_t *
                                                   (const int32_t *) c->in_b.p, count))
         return r;
     return d2h(c, out, c->outb.p, pb);
+}
+
+// ---- netlist level on a device-resident ciphertext pool ---------------------------------------
+int tfhe_hip_gate_level_dev(tfhe_hip_ctx *c, int32_t *d_pool, int64_t pool_rows, const int32_t *gates, int64_t count) {
+    if (int r = check_ctx(c, true)) return r;
+    if (count < 0 || pool_rows < 0 || (count > 0 && (!d_pool || !gates))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    c->ev_br = c->ev_ks = false;
+    if (count == 0) return TFHE_HIP_OK;
+    // validation: indices in range; a level reads the pool as it was before the call, so no row may be both
+    // written and read (or written twice) within one level
+    c->h_mark.assign((size_t) pool_rows, 0);
+    for (int64_t g = 0; g < count; g++) {
+        const int32_t *d = gates + 5 * g;
+        const int gate = d[0];
+        if (gate < TFHE_HIP_NAND || gate > TFHE_HIP_CONST0) return fail(TFHE_HIP_ERR_ARG, "unknown gate id in level");
+        const int nin = gate <= TFHE_HIP_ORYN ? 2 : gate == TFHE_HIP_MUX ? 3 : (gate <= TFHE_HIP_COPY ? 1 : 0);
+        if (d[1] < 0 || d[1] >= pool_rows) return fail(TFHE_HIP_ERR_ARG, "output row out of range");
+        for (int k = 0; k < nin; k++)
+            if (d[2 + k] < 0 || d[2 + k] >= pool_rows) return fail(TFHE_HIP_ERR_ARG, "input row out of range");
+        if (c->h_mark[d[1]] & 1) return fail(TFHE_HIP_ERR_ARG, "row written twice in one level");
+        c->h_mark[d[1]] |= 1;
+    }
+    for (int64_t g = 0; g < count; g++) {
+        const int32_t *d = gates + 5 * g;
+        const int nin = d[0] <= TFHE_HIP_ORYN ? 2 : d[0] == TFHE_HIP_MUX ? 3 : (d[0] <= TFHE_HIP_COPY ? 1 : 0);
+        for (int k = 0; k < nin; k++)
+            if (c->h_mark[d[2 + k]] & 1) return fail(TFHE_HIP_ERR_ARG, "row read and written in the same level");
+    }
+    c->h_br.clear(); c->h_ks.clear(); c->h_lin.clear();
+    for (int64_t g = 0; g < count; g++) {
+        const int32_t *d = gates + 5 * g;
+        GateLin gl;
+        if (gate_lin(d[0], gl)) {
+            c->h_ks.push_back(KsJob{(int32_t) c->h_br.size(), -1, 0, d[1]});
+            c->h_br.push_back(BrJob{d[2], d[3], gl.sa, gl.sb, gl.cst, 0, 0, 0});
+        } else if (d[0] == TFHE_HIP_MUX) {  // boot-gates.cpp:329-370
+            c->h_ks.push_back(KsJob{(int32_t) c->h_br.size(), (int32_t) c->h_br.size() + 1, kMU, d[1]});
+            c->h_br.push_back(BrJob{d[2], d[3], 1, 1, -kMU, 0, 0, 0});
+            c->h_br.push_back(BrJob{d[2], d[4], -1, 1, -kMU, 0, 0, 0});
+        } else {
+            c->h_lin.push_back(d[0]); c->h_lin.push_back(d[1]); c->h_lin.push_back(d[2]);
+        }
+    }
+    const long long nbr = (long long) c->h_br.size(), nks = (long long) c->h_ks.size(), nlin = (long long) c->h_lin.size() / 3;
+    if (nlin) {
+        HIPCHK(c->jobs_lin.reserve(c->h_lin.size() * sizeof(int32_t)));
+        HIPCHK(hipMemcpyAsync(c->jobs_lin.p, c->h_lin.data(), c->h_lin.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_linear_level, dim3((unsigned) nlin), dim3(256), 0, c->stream, d_pool,
+                           (const int32_t *) c->jobs_lin.p, kMU, nlin);
+        HIPCHK(hipGetLastError());
+    }
+    if (nbr) {
+        HIPCHK(c->jobs_br.reserve((size_t) nbr * sizeof(BrJob)));
+        HIPCHK(c->jobs_ks.reserve((size_t) nks * sizeof(KsJob)));
+        HIPCHK(hipMemcpyAsync(c->jobs_br.p, c->h_br.data(), (size_t) nbr * sizeof(BrJob), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->jobs_ks.p, c->h_ks.data(), (size_t) nks * sizeof(KsJob), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c->ext1.reserve((size_t) nbr * kExt * sizeof(int32_t)));
+        BrArgs A{};
+        A.jobs = (const BrJob *) c->jobs_br.p; A.a = d_pool; A.mu = kMU; A.out = (int32_t *) c->ext1.p;
+        A.bk = c->bk; A.tw = c->tw; A.ka = c->ka; A.B = nbr;
+        HIPCHK(hipEventRecord(c->ev[0], c->stream));
+        if (int r = launch_br<MODE_GATE>(c, A)) return r;
+        HIPCHK(hipEventRecord(c->ev[1], c->stream));
+        c->ev_br = true;
+        HIPCHK(hipEventRecord(c->ev[2], c->stream));
+        if (int r = launch_ks(c, d_pool, (const int32_t *) c->ext1.p, nks, (const KsJob *) c->jobs_ks.p)) return r;
+        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        c->ev_ks = true;
+    }
+    // the job lists live in pageable host vectors that the next call overwrites: wait for the copies (and the level)
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TFHE_HIP_OK;
+}
+
+// device-memory helpers so that C callers of the *_dev entry points need no HIP of their own
+int tfhe_hip_dev_alloc(tfhe_hip_ctx *c, size_t bytes, void **out) {
+    if (int r = check_ctx(c, false)) return r;
+    if (!out) return fail(TFHE_HIP_ERR_ARG, "null out pointer");
+    HIPCHK(hipMalloc(out, bytes ? bytes : 1));
+    return TFHE_HIP_OK;
+}
+int tfhe_hip_dev_free(tfhe_hip_ctx *c, void *p) {
+    if (int r = check_ctx(c, false)) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(p));
+    return TFHE_HIP_OK;
+}
+int tfhe_hip_copy_to_dev(tfhe_hip_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (int r = check_ctx(c, false)) return r;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TFHE_HIP_OK;
+}
+int tfhe_hip_copy_from_dev(tfhe_hip_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (int r = check_ctx(c, false)) return r;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TFHE_HIP_OK;
 }
 
 }  // extern "C"

@@ -53,7 +53,8 @@ EXPORTS = [
     "tfhe_hip_gate_batch_dev", "tfhe_hip_bootstrap_batch_dev", "tfhe_hip_keyswitch_batch_dev", "tfhe_hip_sync",
     "tfhe_hip_stream", "tfhe_hip_last_kernel_ms", "tfhe_hip_blind_rotate_batch", "tfhe_hip_extern_mul_batch",
     "tfhe_hip_int_ifft_batch", "tfhe_hip_torus_ifft_batch", "tfhe_hip_torus_fft_batch",
-    "tfhe_hip_negacyclic_mul_batch", "tfhe_hip_negacyclic_mul_batch_dev",
+    "tfhe_hip_negacyclic_mul_batch", "tfhe_hip_negacyclic_mul_batch_dev", "tfhe_hip_gate_level_dev",
+    "tfhe_hip_dev_alloc", "tfhe_hip_dev_free", "tfhe_hip_copy_to_dev", "tfhe_hip_copy_from_dev",
 ]
 
 
@@ -182,6 +183,32 @@ class Engine:
         self._chk(self.lib.tfhe_hip_negacyclic_mul_batch_dev(self.ctx, self._dptr(out), self._dptr(ipolys),
                                                              self._dptr(tpolys), ctypes.c_int64(count)),
                   "negacyclic_mul_batch_dev")
+
+    def gate_level_dev(self, pool, pool_rows, gates):
+        """one netlist level on a device-resident pool; gates: int32[count][5] = gate, out, a, b, c (host)"""
+        g = np.ascontiguousarray(gates, dtype=np.int32).reshape(-1, 5)
+        self._chk(self.lib.tfhe_hip_gate_level_dev(self.ctx, self._dptr(pool), ctypes.c_int64(pool_rows), _p(g),
+                                                   ctypes.c_int64(g.shape[0])), "gate_level_dev")
+
+    # device memory without torch (C callers use the same four functions)
+    def dev_alloc(self, nbytes):
+        ptr = ctypes.c_void_p()
+        self._chk(self.lib.tfhe_hip_dev_alloc(self.ctx, ctypes.c_size_t(nbytes), ctypes.byref(ptr)), "dev_alloc")
+        return ptr.value
+
+    def dev_free(self, ptr):
+        self._chk(self.lib.tfhe_hip_dev_free(self.ctx, ctypes.c_void_p(ptr)), "dev_free")
+
+    def to_dev(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.lib.tfhe_hip_copy_to_dev(self.ctx, ctypes.c_void_p(ptr), _p(arr), ctypes.c_size_t(arr.nbytes)),
+                  "copy_to_dev")
+
+    def from_dev(self, ptr, shape, dtype=np.int32):
+        out = np.empty(shape, dtype=dtype)
+        self._chk(self.lib.tfhe_hip_copy_from_dev(self.ctx, _p(out), ctypes.c_void_p(ptr), ctypes.c_size_t(out.nbytes)),
+                  "copy_from_dev")
+        return out
 
     def sync(self):
         self._chk(self.lib.tfhe_hip_sync(self.ctx), "sync")
