@@ -131,10 +131,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)       # == local_rank on a full node; lets 2 ranks rehearse on a 1-GPU box
+    torch.cuda.set_device(dev_index)            # torch first, then the engine: both then share one HIP runtime
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("TFHE_BENCH_BACKEND", "nccl")   # "gloo" only for the 1-GPU rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.workload != "nand":
         return side_bench(args, torch, dev, rank, world)
@@ -142,8 +148,9 @@ def main():
     client = Client()
     # ---- keys: generated once (rank 0), replicated to every GPU by an RCCL broadcast -------------------------
     from tfhe_amd.parallel import broadcast_keys
-    keys = broadcast_keys(client.keygen(42) if rank == 0 else None, device=dev)
-    eng = Engine(local_rank)
+    cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")   # collective tensors
+    keys = broadcast_keys(client.keygen(42) if rank == 0 else None, device=cdev)
+    eng = Engine(dev_index)
     eng.load_keys_coef(keys.bk_coef, keys.ks)
 
     # ---- synthetic inputs: fresh encryptions of iid random bits, resident in HBM -----------------------------
@@ -181,7 +188,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -189,7 +196,7 @@ def main():
     got = d_out.cpu().numpy()
     dec, phases = client.decrypt(keys, got)
     n_bad = int((dec != expect).sum())
-    ok_flag = torch.tensor([n_bad], dtype=torch.int64, device=dev)
+    ok_flag = torch.tensor([n_bad], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(ok_flag)
     total_bad = int(ok_flag.item())
