@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 #include <random>
+#include <climits>
 #include "../../tfhe_amd/csrc/br_core.h"
 #include "../../oracle/tfhe_oracle.h"
 using namespace brc;
@@ -95,6 +96,25 @@ int main() {
         emu_inverse(C, r2, true);
         { int nd = 0; for (int i = 0; i < 1024; i++) if (r1[i] != r2[i]) nd++;
           if (nd) { bad++; if (bad < 8) printf("inverse(bounded) trial %d: %d coefficients differ\n", trial, nd); } }
+    }
+    {   // gadget decomposition: prepared-word form == reference form (tgsw-functions.cpp:297-315)
+        int32_t t[1024], want[3 * 1024];
+        for (int i = 0; i < 1024; i++) t[i] = (int32_t) rng();
+        t[0] = 0; t[1] = -1; t[2] = INT32_MIN; t[3] = INT32_MAX; t[4] = (int32_t) (0u - kDecompOffset);
+        oracle_decompH(want, t);
+        for (int p = 0; p < 3; p++)
+            for (int i = 0; i < 1024; i++)
+                if (decomp_digit(decomp_prepare(t[i]), p) != want[p * 1024 + i]) { bad++; break; }
+        // (X^a - 1) * acc, modulus switch
+        for (int a : {0, 1, 511, 1023, 1024, 1025, 2047}) {
+            int32_t w[1024];
+            oracle_mulByXaiMinusOne(w, a, t);
+            for (int j = 0; j < 1024; j++) if (rot_minus_one(t, a, j) != w[j]) { bad++; break; }
+        }
+        for (int i = 0; i < 100000; i++) {
+            int32_t x = (int32_t) rng();
+            if (modswitch_2N(x) != oracle_modSwitchFromTorus32(x, 2048)) { bad++; break; }
+        }
     }
     printf(bad ? "EMU FAIL (%d)\n" : "EMU OK\n", bad);
     return bad != 0;

@@ -148,3 +148,27 @@ def test_empty_batch_and_argument_errors(engine):
         engine.gate_batch(Gate.NAND, np.zeros((1, P.n + 1), np.int32), None, count=1)
     with pytest.raises(TfheHipError):
         engine.extern_mul_batch(np.zeros((1, 2, P.N), np.int32), np.array([630], np.int32))
+
+
+def test_full_size_batch_16384_and_mux(engine, client, keys, oracle, okeys):
+    """BASELINE configs[1] at its full size: 16,384 independent NAND gates, every output decrypted, sampled
+    ciphertexts identical to the oracle; plus a MUX batch (configs[4]) whose outputs all decrypt to a ? b : c."""
+    rng = np.random.default_rng(77)
+    count = 16384
+    a, b, c = (rng.integers(0, 2, count).astype(np.uint8) for _ in range(3))
+    ca, cb = client.encrypt(keys, a, 301), client.encrypt(keys, b, 302)
+    got = engine.gate_batch(Gate.NAND, ca, cb)
+    dec, phases = client.decrypt(keys, got)
+    assert np.array_equal(dec, 1 - (a & b))
+    assert np.abs(np.abs(phases.astype(np.int64)) - (1 << 29)).max() < (1 << 28)
+    for i in (0, 8191, 16383):
+        assert np.array_equal(got[i], oracle.gate(okeys, Gate.NAND, ca[i], cb[i])), i
+    # size-independent property: a bootstrapped gate's output depends only on its own inputs (batch position and
+    # batch size do not matter): re-running a slice reproduces the same ciphertexts bit for bit
+    again = engine.gate_batch(Gate.NAND, ca[5000:5100], cb[5000:5100])
+    assert np.array_equal(again, got[5000:5100])
+    m = 4096
+    cc = client.encrypt(keys, c[:m], 303)
+    mux = engine.gate_batch(Gate.MUX, ca[:m], cb[:m], cc)
+    dec, _ = client.decrypt(keys, mux)
+    assert np.array_equal(dec, np.where(a[:m] == 1, b[:m], c[:m]))

@@ -361,10 +361,15 @@ BRC_HD int32_t rot_minus_one(const int32_t *acc, int a, int j) {
     const uint32_t rot = (s & kN) ? (0u - v) : v;
     return (int32_t) (rot - (uint32_t) acc[j]);
 }
-// gadget digit p (0..l-1) of a Torus32: reference tgsw-functions.cpp:297-315
-BRC_HD int32_t decomp_digit(int32_t t, int p) {
-    const uint32_t u = (uint32_t) t + kDecompOffset;
-    return (int32_t) ((u >> (32 - (p + 1) * kBgbit)) & 127u) - 64;
+// gadget digit p (0..l-1) of a Torus32: reference tgsw-functions.cpp:297-315:
+//   u = t + offset;  digit_p = ((u >> (32 - 7(p+1))) & 127) - 64
+// field - 64 equals the field read as a signed 7-bit number after flipping its top bit, so the three digits of one
+// coefficient cost one add, one xor (decomp_prepare, once) and one signed bit-field extract each (decomp_digit).
+BRC_HD uint32_t decomp_prepare(int32_t t) {
+    return ((uint32_t) t + kDecompOffset) ^ ((1u << 31) | (1u << 24) | (1u << 17));
+}
+BRC_HD int32_t decomp_digit(uint32_t prepared, int p) {
+    return ((int32_t) (prepared << (kBgbit * p))) >> (32 - kBgbit);
 }
 // modSwitchFromTorus32(x, 2N): reference numeric-functions.cpp:59-65 (2^64/2N = 2^53 wide intervals)
 BRC_HD int32_t modswitch_2N(int32_t x) { return (int32_t) ((((uint32_t) x) + (1u << 20)) >> 21) & (2 * kN - 1); }

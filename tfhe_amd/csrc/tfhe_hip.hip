@@ -174,17 +174,17 @@ __device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int b
 
 #pragma unroll 1
     for (int c = 0; c < 2; c++) {
-        int32_t tlo[8], thi[8];
+        uint32_t tlo[8], thi[8];  // rotated differences, offset added and digit sign bits flipped (decomp_prepare)
         const int32_t *accc = acc + c * kN;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int j = (br3(r) << 6) | lane;
             if (ROTATE) {
-                tlo[r] = rot_minus_one(accc, bara, j);
-                thi[r] = rot_minus_one(accc, bara, j + kNh);
+                tlo[r] = decomp_prepare(rot_minus_one(accc, bara, j));
+                thi[r] = decomp_prepare(rot_minus_one(accc, bara, j + kNh));
             } else {
-                tlo[r] = accc[j];
-                thi[r] = accc[j + kNh];
+                tlo[r] = decomp_prepare(accc[j]);
+                thi[r] = decomp_prepare(accc[j + kNh]);
             }
         }
 #pragma unroll 1
