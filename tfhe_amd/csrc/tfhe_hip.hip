@@ -375,7 +375,7 @@ __global__ __launch_bounds__(192) void k_keyswitch(const int32_t *__restrict__ i
 // 16-byte loads from the key stored as int8[i][limb][q][j][d].
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kKsQ = 640;     // output coefficients padded to 20 tiles of 32
-constexpr int kKsMT = 4;      // 32-ciphertext tiles per wave
+constexpr int kKsMT = 2;      // 32-ciphertext tiles per wave
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 
@@ -438,9 +438,9 @@ __global__ void k_ks_transpose(uint32_t *__restrict__ abarT, const int32_t *__re
     for (int r = ty; r < 32; r += 8) abarT[(size_t) (i0 + r) * Bp + g0 + tx] = tile[tx][r];
 }
 
-// grid (Bp/128, 5), block 256: wave w of block (x, y) owns ciphertexts [128x, 128x+128) and coefficients
-// [32(4y+w), 32(4y+w)+32)
-__global__ __launch_bounds__(256) void k_keyswitch_mfma(const uint32_t *__restrict__ abarT, const int8_t *__restrict__ kl,
+// grid (Bp/(32*MT), 5), block 256: wave w of block (x, y) owns 32*MT ciphertexts and coefficients
+// [32(4y+w), 32(4y+w)+32); all four limbs accumulate in one pass over i (A fragments built once per i)
+__global__ __launch_bounds__(256, 2) void k_keyswitch_mfma(const uint32_t *__restrict__ abarT, const int8_t *__restrict__ kl,
                                                         const int32_t *__restrict__ in, int32_t *__restrict__ out,
                                                         long long B, long long Bp, const KsJob *__restrict__ kj) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -449,43 +449,31 @@ __global__ __launch_bounds__(256) void k_keyswitch_mfma(const uint32_t *__restri
     const int q = (blockIdx.y * 4 + wave) * 32 + r32;
     const uint32_t *ap = abarT + g0 + r32;
     const v4i_t *bp = reinterpret_cast<const v4i_t *>(kl) + (size_t) q * 2 + h;
-    uint32_t total[kKsMT][16];
+    v16i_t acc[4][kKsMT];
 #pragma unroll
-    for (int m = 0; m < kKsMT; m++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) total[m][r] = 0;
-#pragma unroll 1
-    for (int lp = 0; lp < 2; lp++) {  // two limbs per pass
-        v16i_t acc[2][kKsMT];
-#pragma unroll
-        for (int l = 0; l < 2; l++)
-#pragma unroll
-            for (int m = 0; m < kKsMT; m++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[l][m][r] = 0;
-#pragma unroll 2
-        for (int i = 0; i < kN; i++) {
-            const v4i_t b0 = bp[((size_t) i * 4 + 2 * lp) * kKsQ * 2];
-            const v4i_t b1 = bp[((size_t) i * 4 + 2 * lp + 1) * kKsQ * 2];
-#pragma unroll
-            for (int m = 0; m < kKsMT; m++) {
-                const uint32_t ab = ap[(size_t) i * Bp + 32 * m];
-                v4i_t a;
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    // digit j = 4h + jj: ((ab >> (30 - 2j)) & 3); one-hot byte position = digit
-                    const uint32_t sh = (ab >> (27 - 2 * jj - 8 * h)) & 24u;
-                    a[jj] = (int) (1u << sh);
-                }
-                acc[0][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc[0][m], 0, 0, 0);
-                acc[1][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc[1][m], 0, 0, 0);
-            }
-        }
+    for (int l = 0; l < 4; l++)
 #pragma unroll
         for (int m = 0; m < kKsMT; m++)
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                total[m][r] += ((uint32_t) acc[0][m][r] << (16 * lp)) + ((uint32_t) acc[1][m][r] << (16 * lp + 8));
+            for (int r = 0; r < 16; r++) acc[l][m][r] = 0;
+#pragma unroll 2
+    for (int i = 0; i < kN; i++) {
+        v4i_t b[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) b[l] = bp[((size_t) i * 4 + l) * kKsQ * 2];
+#pragma unroll
+        for (int m = 0; m < kKsMT; m++) {
+            const uint32_t ab = ap[(size_t) i * Bp + 32 * m];
+            v4i_t a;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                // digit j = 4h + jj: ((ab >> (30 - 2j)) & 3); one-hot byte position = digit
+                const uint32_t sh = (ab >> (27 - 2 * jj - 8 * h)) & 24u;
+                a[jj] = (int) (1u << sh);
+            }
+#pragma unroll
+            for (int l = 0; l < 4; l++) acc[l][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[l], acc[l][m], 0, 0, 0);
+        }
     }
     if (q > kLwe) return;
 #pragma unroll
@@ -494,6 +482,8 @@ __global__ __launch_bounds__(256) void k_keyswitch_mfma(const uint32_t *__restri
         for (int r = 0; r < 16; r++) {
             const long long g = g0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (g < B) {
+                const uint32_t total = (uint32_t) acc[0][m][r] + ((uint32_t) acc[1][m][r] << 8) +
+                                       ((uint32_t) acc[2][m][r] << 16) + ((uint32_t) acc[3][m][r] << 24);
                 uint32_t init = 0u;
                 long long orow = g;
                 if (kj) {
@@ -506,7 +496,7 @@ __global__ __launch_bounds__(256) void k_keyswitch_mfma(const uint32_t *__restri
                 } else if (q == kLwe) {
                     init = (uint32_t) in[g * kExt + kN];
                 }
-                out[orow * kCt + q] = (int32_t) (init - total[m][r]);
+                out[orow * kCt + q] = (int32_t) (init - total);
             }
         }
 }
@@ -803,11 +793,11 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A) {
 int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B, const KsJob *kj = nullptr) {
     if (B <= 0) return TFHE_HIP_OK;
     if (c->ks_mfma || kj) {
-        const long long Bp = (B + 127) / 128 * 128;
+        const long long Bp = (B + 32 * kKsMT - 1) / (32 * kKsMT) * (32 * kKsMT);
         HIPCHK(c->abart.reserve((size_t) kN * Bp * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_ks_transpose, dim3((unsigned) (Bp / 32), kN / 32), dim3(256), 0, c->stream,
                            (uint32_t *) c->abart.p, d_in, B, Bp, kj);
-        hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) (Bp / 128), 5), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) (Bp / (32 * kKsMT)), 5), dim3(256), 0, c->stream,
                            (const uint32_t *) c->abart.p, (const int8_t *) c->kl, d_in, d_out, B, Bp, kj);
     } else {
         dim3 grid((unsigned) ((B + kKsG - 1) / kKsG));
