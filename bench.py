@@ -241,7 +241,10 @@ def main():
                        "outputs_decrypt_correctly": True},
             "per_gate_latency_ms": lat_ms,
             "kernel_ms": {"blind_rotate": br_avg, "keyswitch": float(np.mean(ks_ms))},
-            "roofline": {"bound": "fp64_valu", "kernel": "k_blind_rotate", "achieved": achieved,
+            "roofline": {"bound": "mfma", "bound_detail": "FP64 compute: the work runs on the FP64 vector ALUs, whose "
+                         "78.6 TFLOP/s FMA peak equals the FP64 MFMA peak; the bit-exact contract forbids FMA, so "
+                         "separate mul/add can reach at most half of it", "kernel": "k_blind_rotate",
+                         "achieved": achieved,
                          "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                          "flop_per_launch": FLOP_PER_BOOTSTRAP * B, "launch_ms": br_avg},
