@@ -326,3 +326,83 @@ extern "C" void ref_gate_batch(int32_t gate, int32_t *out, const int32_t *a, con
     }
     for (int t = 0; t < nthreads; t++) pthread_join(th[t], nullptr);
 }
+
+// ---- the reference's own wire formats (tfhe_io.cpp), used to pin tfhe_amd/csrc/wire_io.cpp -----------------------
+#include <cstdio>
+extern "C" {
+// export_tfheGateBootstrappingCloudKeySet_toFile (tfhe_io.cpp:1109) of the installed keys
+int32_t ref_export_cloud_keyset(const char *path) {
+    FILE *F = fopen(path, "wb");
+    if (!F) return -1;
+    export_tfheGateBootstrappingCloudKeySet_toFile(F, &g_keys->cloud);
+    fclose(F);
+    return 0;
+}
+// new_tfheGateBootstrappingCloudKeySet_fromFile (tfhe_io.cpp:1117), flattened; the key lives until the next call
+static TFheGateBootstrappingCloudKeySet *g_cloud_in = nullptr;
+int32_t ref_import_cloud_keyset(const char *path, int32_t *bk_coef, int32_t *ks) {
+    FILE *F = fopen(path, "rb");
+    if (!F) return -1;
+    if (g_cloud_in) delete_gate_bootstrapping_cloud_keyset(g_cloud_in);
+    g_cloud_in = new_tfheGateBootstrappingCloudKeySet_fromFile(F);
+    fclose(F);
+    const LweBootstrappingKey *bk = g_cloud_in->bk;
+    for (int i = 0; i < n_; i++)
+        for (int p = 0; p < kpl_; p++)
+            for (int c = 0; c < 2; c++)
+                memcpy(bk_coef + (((size_t) i * kpl_ + p) * 2 + c) * N_, bk->bk[i].all_sample[p].a[c].coefsT,
+                       sizeof(int32_t) * N_);
+    for (int i = 0; i < N_; i++)
+        for (int j = 0; j < t_; j++)
+            for (int d = 0; d < base_; d++)
+                from_sample(ks + (((size_t) i * t_ + j) * base_ + d) * (n_ + 1), &bk->ks->ks[i][j][d], n_);
+    return 0;
+}
+// a NAND on the imported cloud key (shows that a file written by the build is a working key for the reference)
+void ref_imported_nand(int32_t *out, const int32_t *a, const int32_t *b) {
+    LweSample *sa = new_LweSample(g_params->in_out_params), *sb = new_LweSample(g_params->in_out_params),
+              *so = new_LweSample(g_params->in_out_params);
+    to_sample(sa, a, n_);
+    to_sample(sb, b, n_);
+    bootsNAND(so, sa, sb, g_cloud_in);
+    from_sample(out, so, n_);
+    delete_LweSample(sa); delete_LweSample(sb); delete_LweSample(so);
+}
+// export_gate_bootstrapping_ciphertext_toFile (tfhe_io.cpp:1214) in a loop, variance[i] stored with each sample
+int32_t ref_export_ciphertexts(const char *path, const int32_t *flat, const double *variance, int32_t count) {
+    ensure_params();
+    FILE *F = fopen(path, "wb");
+    if (!F) return -1;
+    LweSample *s = new_LweSample(g_params->in_out_params);
+    for (int i = 0; i < count; i++) {
+        to_sample(s, flat + (size_t) i * (n_ + 1), n_);
+        s->current_variance = variance ? variance[i] : 0.;
+        export_gate_bootstrapping_ciphertext_toFile(F, s, g_params);
+    }
+    delete_LweSample(s);
+    fclose(F);
+    return 0;
+}
+int32_t ref_import_ciphertexts(const char *path, int32_t *flat, double *variance, int32_t count) {
+    ensure_params();
+    FILE *F = fopen(path, "rb");
+    if (!F) return -1;
+    LweSample *s = new_LweSample(g_params->in_out_params);
+    for (int i = 0; i < count; i++) {
+        import_gate_bootstrapping_ciphertext_fromFile(F, s, g_params);
+        from_sample(flat + (size_t) i * (n_ + 1), s, n_);
+        if (variance) variance[i] = s->current_variance;
+    }
+    delete_LweSample(s);
+    fclose(F);
+    return 0;
+}
+int32_t ref_export_params(const char *path) {
+    ensure_params();
+    FILE *F = fopen(path, "wb");
+    if (!F) return -1;
+    export_tfheGateBootstrappingParameterSet_toFile(F, g_params);
+    fclose(F);
+    return 0;
+}
+}  // extern "C"

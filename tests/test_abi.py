@@ -58,6 +58,7 @@ def test_null_arguments_are_rejected():
 def test_product_does_not_touch_the_oracle():
     """the shipped path must not import, link or load anything under oracle/"""
     for rel in ("tfhe_amd/engine.py", "tfhe_amd/client.py", "tfhe_amd/__init__.py", "tfhe_amd/csrc/tfhe_hip.hip",
-                "tfhe_amd/csrc/br_core.h", "tfhe_amd/csrc/client_keys.c"):
+                "tfhe_amd/csrc/br_core.h", "tfhe_amd/csrc/client_keys.c", "tfhe_amd/csrc/wire_io.cpp",
+                "tfhe_amd/csrc/compat_libtfhe.cpp", "tfhe_amd/wire.py", "tfhe_amd/netlist.py", "tfhe_amd/parallel.py"):
         text = open(os.path.join(ROOT, rel)).read()
         assert "liboracle" not in text and "tfhe_oracle" not in text and "oracle_lib" not in text, rel

@@ -4,3 +4,4 @@ Python here is plumbing over the C-ABI library (include/tfhe_hip.h); the product
 """
 from .engine import Engine, Gate, TfheHipError, PARAMS  # noqa: F401
 from .client import Client, KeySet  # noqa: F401
+from . import wire  # noqa: F401

@@ -29,15 +29,16 @@ def _stale(target, sources):
 def build_hip(force=False):
     out = os.path.join(ROOT, "tfhe_amd", "libtfhe_hip.so")
     srcs = [os.path.join(CSRC, "tfhe_hip.hip"), os.path.join(CSRC, "br_core.h"),
-            os.path.join(CSRC, "compat_libtfhe.cpp"), os.path.join(ROOT, "include", "tfhe_hip.h"),
-            os.path.join(ROOT, "include", "tfhe_hip_compat.h")]
+            os.path.join(CSRC, "compat_libtfhe.cpp"), os.path.join(CSRC, "wire_io.cpp"),
+            os.path.join(CSRC, "internal.h"), os.path.join(ROOT, "include", "tfhe_hip.h"),
+            os.path.join(ROOT, "include", "tfhe_hip_compat.h"), os.path.join(ROOT, "include", "tfhe_hip_io.h")]
     srcs = [s for s in srcs if os.path.exists(s)]
     if force or _stale(out, srcs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-I" + os.path.join(ROOT, "include"), "-o", out, os.path.join(CSRC, "tfhe_hip.hip")]
-        compat = os.path.join(CSRC, "compat_libtfhe.cpp")
-        if os.path.exists(compat):
-            cmd.append(compat)
+        for extra in ("compat_libtfhe.cpp", "wire_io.cpp"):
+            if os.path.exists(os.path.join(CSRC, extra)):
+                cmd.append(os.path.join(CSRC, extra))
         _run(cmd)
     return out
 

@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 #include "br_core.h"
+#include "internal.h"
 #include "../../include/tfhe_hip.h"
 
 #pragma clang fp contract(off)
@@ -849,6 +850,8 @@ int upload_ks(tfhe_hip_ctx *c, const int32_t *ks) {
 }
 
 }  // namespace
+
+int tfhe_hip_internal_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
 
 extern "C" {
 
