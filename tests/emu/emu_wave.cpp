@@ -12,6 +12,9 @@
 using namespace brc;
 
 static std::vector<c64> g_tw(kTwEntries);
+static std::vector<c64> g_lane_tw(kTwLaneEntries);
+struct TW { c64 operator()(int i) const { return g_tw[i]; } };        // base tables
+struct TWL { int lane; c64 operator()(int slot) const { return g_lane_tw[slot * 64 + lane]; } };  // per-lane image
 static void init_tw() {
     int L = oracle_trig_table_len();
     std::vector<double> rev(L), dir(L);
@@ -24,8 +27,8 @@ static void init_tw() {
         }
         off += size;
     }
+    build_lane_twiddles(g_lane_tw.data(), TW{});
 }
-struct TW { c64 operator()(int i) const { return g_tw[i]; } };
 
 static void emu_forward(const double *p, c64 *logical_out) {
     static c64 v[64][8], scratch[512];
@@ -35,10 +38,10 @@ static void emu_forward(const double *p, c64 *logical_out) {
     for (int l = 0; l < 64; l++) fwd_phaseA(v[l], kc);
     for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) scratch[swz(fwd_xA(l, r))] = v[l][r];
     for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) v[l][r] = scratch[swz(fwd_xB(l, r))];
-    for (int l = 0; l < 64; l++) fwd_phaseB(v[l], l, tw);
+    for (int l = 0; l < 64; l++) fwd_phaseB(v[l], TWL{l});
     for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) scratch[swz(fwd_xB(l, r))] = v[l][r];
     for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) v[l][r] = scratch[swz(fwd_xC(l, r))];
-    for (int l = 0; l < 64; l++) fwd_phaseC(v[l], l, tw);
+    for (int l = 0; l < 64; l++) fwd_phaseC(v[l], TWL{l});
     for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) logical_out[igray(fwd_xC(l, r))] = v[l][r];
 }
 
@@ -53,11 +56,11 @@ static void emu_inverse(const c64 *C /*logical*/, int32_t *out, bool bounded) {
     for (int l = 0; l < 64; l++) inv_phaseA(v[l], kc);
     for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) scratch[inv_yA(l, r)] = v[l][r];
     for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) v[l][r] = scratch[inv_yB(l, r)];
-    for (int l = 0; l < 64; l++) inv_phaseB(v[l], l, tw);
+    for (int l = 0; l < 64; l++) inv_phaseB(v[l], TWL{l});
     for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) scratch[inv_yB(l, r)] = v[l][r];
     for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) v[l][r] = scratch[inv_yC(l, r)];
-    for (int l = 0; l < 64; l++) inv_phaseC(v[l], l, tw);
-    for (int l = 0; l < 64; l++) { int32_t o[16]; if (bounded) inv_final<true>(o, v[l], l, tw); else inv_final<false>(o, v[l], l, tw); for (int r = 0; r < 16; r++) out[inv_yC(l, r)] = o[r]; }
+    for (int l = 0; l < 64; l++) inv_phaseC(v[l], TWL{l});
+    for (int l = 0; l < 64; l++) { int32_t o[16]; if (bounded) inv_final<true>(o, v[l], TWL{l}); else inv_final<false>(o, v[l], TWL{l}); for (int r = 0; r < 16; r++) out[inv_yC(l, r)] = o[r]; }
 }
 
 int main() {

@@ -43,7 +43,13 @@ constexpr int kL = 3;          // decomposition length
 constexpr int kKpl = 6;        // (k+1)*l rows
 constexpr int kBgbit = 7;
 constexpr uint32_t kDecompOffset = 2164391936u;  // reference src/include/tfhe_core.h:24
-constexpr int kTwEntries = 2044;                 // sizes 8..2048: sum of size/2
+constexpr int kTwEntries = 2044;                 // base tables, sizes 8..2048: sum of size/2
+// Per-lane twiddle image kept in LDS: 31 slots x 64 lanes; slot s of lane l sits at [s*64 + l], so every table read of
+// the lane-dependent phases is `lane base + constant` (one address register, immediate offsets) and the 64 lanes of
+// a wave read 64 consecutive 16-byte entries (no bank conflicts).  Which base-table entry goes where: tw_slot_index.
+constexpr int kTwSlots = 31;
+constexpr int kTwLaneEntries = kTwSlots * 64;    // 1984 c64 = 31,744 bytes
+enum { TWS_FB = 0, TWS_FC = 4, TWS_IB = 8, TWS_IC = 15, TWS_FIN = 23 };
 
 struct alignas(16) c64 {
     double re, im;
@@ -64,6 +70,36 @@ BRC_HD constexpr int igray(int u) {
     return u;
 }
 BRC_HD constexpr int gray(int u) { return u ^ (u >> 1); }
+
+// Base-table index held in slot `slot` of lane `lane` (layouts of the phases: see below).  Only entries of the first
+// quarter turn are stored; the others follow from two exact symmetries of the reference table (octant folding,
+// src/include/tfhe_core.h:26,93):   table(n, n/4 - j) = (sin_j, cos_j)      ("mirror", used by the forward phases)
+//                                   table(n, n/4 + j) = (-sin_j, cos_j)     ("quarter", used by the inverse phases)
+BRC_HD int tw_slot_index(int slot, int lane) {
+    const int l3 = lane & 7, g3 = igray(l3), g6 = igray(lane), low = ((lane >> 3) << 4) | l3;
+    if (slot == 0) return tw_idx(64, 2 * g3 + 1);                      // forward level 3
+    if (slot == 1) return tw_idx(128, 2 * g3 + 1);                     // forward level 4
+    if (slot == 2) return tw_idx(256, 2 * g3 + 1);                     // forward level 5, x4x3 = 00
+    if (slot == 3) return tw_idx(256, 2 * (16 | g3) + 1);              //                   x4x3 = 11
+    if (slot == 4) return tw_idx(512, 2 * g6 + 1);                     // forward level 6
+    if (slot == 5) return tw_idx(1024, 2 * g6 + 1);                    // forward level 7
+    if (slot == 6) return tw_idx(2048, 2 * g6 + 1);                    // forward level 8, x7x6 = 00
+    if (slot == 7) return tw_idx(2048, 2 * (128 | g6) + 1);            //                   x7x6 = 11
+    if (slot == 8) return tw_idx(32, l3);                              // inverse level 4, y3 = 0
+    if (slot < 11) return tw_idx(64, ((slot - 9) << 3) | l3);          // inverse level 5, y4 = 0, y3 = slot-9
+    if (slot < 15) return tw_idx(128, ((slot - 11) << 3) | l3);        // inverse level 6, y5 = 0, (y4 y3) = slot-11
+    if (slot < 17) return tw_idx(256, low | ((slot - 15) << 3));       // inverse level 7, y3 = slot-15
+    if (slot < 19) return tw_idx(512, low | ((slot - 17) << 3));       // inverse level 8, y7 = 0, y3 = slot-17
+    if (slot < 23) return tw_idx(1024, (((slot - 19) >> 1) << 7) | low | (((slot - 19) & 1) << 3));  // level 9, y8 = 0
+    const int rho = slot - 23;                                         // last merge, y9 = 0 (rho < 8)
+    return tw_idx(2048, ((rho >> 1) << 7) | low | ((rho & 1) << 3));
+}
+// lane image from the base tables; BASE: (index) -> c64
+template <class BASE>
+inline void build_lane_twiddles(c64 *out /*[kTwLaneEntries]*/, const BASE &base) {
+    for (int s = 0; s < kTwSlots; s++)
+        for (int l = 0; l < 64; l++) out[s * 64 + l] = base(tw_slot_index(s, l));
+}
 
 // ---- LDS scratch swizzle (slot = 16-byte element index inside the wave's 8 KB scratch) ------------------------
 // XORs slot bits 6..8 into bits 0..2 and bit 7 into bit 3.  With it every ds_write_b128 / ds_read_b128 of the three
@@ -91,6 +127,18 @@ BRC_HD void inv_bf(c64 &E, c64 &O, const c64 w) {
     E = lo;
     O = hi;
 }
+
+// inverse butterfly with the twiddle a quarter turn after w: table(n, j + n/4) = (-s, c) for w = table(n, j) = (c, s).
+// Value-identical to inv_bf with that entry: Or*(-s) + Oi*c = Oi*c - Or*s and Oi*(-s) - Or*c = -(Oi*s) - Or*c exactly.
+BRC_HD void inv_bf_q(c64 &E, c64 &O, const c64 w) {
+    const double tr = O.im * w.re - O.re * w.im;
+    const double ti = -(O.im * w.im) - O.re * w.re;
+    const c64 lo = {E.re + tr, E.im + ti};
+    const c64 hi = {E.re - tr, E.im - ti};
+    E = lo;
+    O = hi;
+}
+BRC_HD c64 mirror(const c64 w) { return {w.im, w.re}; }  // table(n, n/4 - j) from table(n, j)
 
 // =================================================================================================================
 // FORWARD TRANSFORM, 512 complex values, 8 per lane.
@@ -145,61 +193,53 @@ BRC_HD int fwd_xA(int lane, int r) { return (br6(lane) << 3) | r; }
 BRC_HD int fwd_xB(int lane, int r) { return ((lane >> 3) << 6) | (r << 3) | (lane & 7); }
 BRC_HD int fwd_xC(int lane, int r) { return (r << 6) | lane; }
 
-template <class TW>  // TW: (index) -> c64, lane-varying indices (LDS table)
-BRC_HD void fwd_phaseB(c64 (&v)[8], int lane, const TW &tw) {
-    const int g3 = igray(lane & 7);  // igray of x2x1x0
-    {   // level 3, size 64: q = 2*g3+1
-        const c64 w = tw(tw_idx(64, 2 * g3 + 1));
+template <class TW>  // TW: (slot) -> this lane's entry of the per-lane twiddle image
+BRC_HD void fwd_phaseB(c64 (&v)[8], const TW &tw) {
+    {   // level 3, size 64: q = 2*g3+1, g3 = igray(x2x1x0)
+        const c64 w = tw(TWS_FB + 0);
 #pragma unroll
         for (int r = 0; r < 8; r += 2) fwd_bf(v[r], v[r + 1], w);
     }
-    {   // level 4, size 128: u = (x3, x2x1x0): m = x3<<3 | (g3 ^ (x3?7:0))
-        const c64 w0 = tw(tw_idx(128, 2 * g3 + 1));
-        const c64 w1 = tw(tw_idx(128, 2 * (8 | (g3 ^ 7)) + 1));
+    {   // level 4, size 128: m = x3<<3 | (g3 ^ (x3?7:0)) = g3 or 15-g3: the second is the mirror of the first
+        const c64 w0 = tw(TWS_FB + 1);
+        const c64 w1 = mirror(w0);
 #pragma unroll
         for (int g = 0; g < 8; g += 4) {
             fwd_bf(v[g + 0], v[g + 2], w0);
             fwd_bf(v[g + 1], v[g + 3], w1);
         }
     }
-    {   // level 5, size 256: u = (x4 x3, x2x1x0): m = igray2(x4x3)<<3 | (g3 ^ (parity?7:0))
-        const c64 w0 = tw(tw_idx(256, 2 * ((0 << 3) | g3) + 1));        // x4x3 = 00
-        const c64 w1 = tw(tw_idx(256, 2 * ((1 << 3) | (g3 ^ 7)) + 1));  // 01
-        const c64 w2 = tw(tw_idx(256, 2 * ((3 << 3) | (g3 ^ 7)) + 1));  // 10
-        const c64 w3 = tw(tw_idx(256, 2 * ((2 << 3) | g3) + 1));        // 11
-        fwd_bf(v[0], v[4], w0);
-        fwd_bf(v[1], v[5], w1);
-        fwd_bf(v[2], v[6], w2);
-        fwd_bf(v[3], v[7], w3);
+    {   // level 5, size 256: m = g3, 15-g3, 31-g3, 16+g3 for x4x3 = 00, 01, 10, 11; 31-m mirrors m
+        const c64 a = tw(TWS_FB + 2), d = tw(TWS_FB + 3);
+        fwd_bf(v[0], v[4], a);
+        fwd_bf(v[1], v[5], mirror(d));
+        fwd_bf(v[2], v[6], mirror(a));
+        fwd_bf(v[3], v[7], d);
     }
 }
 
 template <class TW>
-BRC_HD void fwd_phaseC(c64 (&v)[8], int lane, const TW &tw) {
-    const int g6 = igray(lane);  // igray of x5..x0
-    {   // level 6, size 512
-        const c64 w = tw(tw_idx(512, 2 * g6 + 1));
+BRC_HD void fwd_phaseC(c64 (&v)[8], const TW &tw) {
+    {   // level 6, size 512: q = 2*g6+1, g6 = igray(x5..x0)
+        const c64 w = tw(TWS_FC + 0);
 #pragma unroll
         for (int r = 0; r < 8; r += 2) fwd_bf(v[r], v[r + 1], w);
     }
-    {   // level 7, size 1024
-        const c64 w0 = tw(tw_idx(1024, 2 * g6 + 1));
-        const c64 w1 = tw(tw_idx(1024, 2 * (64 | (g6 ^ 63)) + 1));
+    {   // level 7, size 1024: m = g6 or 127-g6
+        const c64 w0 = tw(TWS_FC + 1);
+        const c64 w1 = mirror(w0);
 #pragma unroll
         for (int g = 0; g < 8; g += 4) {
             fwd_bf(v[g + 0], v[g + 2], w0);
             fwd_bf(v[g + 1], v[g + 3], w1);
         }
     }
-    {   // level 8, size 2048
-        const c64 w0 = tw(tw_idx(2048, 2 * ((0 << 6) | g6) + 1));
-        const c64 w1 = tw(tw_idx(2048, 2 * ((1 << 6) | (g6 ^ 63)) + 1));
-        const c64 w2 = tw(tw_idx(2048, 2 * ((3 << 6) | (g6 ^ 63)) + 1));
-        const c64 w3 = tw(tw_idx(2048, 2 * ((2 << 6) | g6) + 1));
-        fwd_bf(v[0], v[4], w0);
-        fwd_bf(v[1], v[5], w1);
-        fwd_bf(v[2], v[6], w2);
-        fwd_bf(v[3], v[7], w3);
+    {   // level 8, size 2048: m = g6, 127-g6, 255-g6, 128+g6 for x7x6 = 00, 01, 10, 11; 255-m mirrors m
+        const c64 a = tw(TWS_FC + 2), d = tw(TWS_FC + 3);
+        fwd_bf(v[0], v[4], a);
+        fwd_bf(v[1], v[5], mirror(d));
+        fwd_bf(v[2], v[6], mirror(a));
+        fwd_bf(v[3], v[7], d);
     }
 }
 
@@ -237,7 +277,7 @@ BRC_HD void inv_bf_neg(c64 &E, c64 &O, const double c, const double s) {  // w =
     O = hi;
 }
 
-BRC_HD void inv_phaseA(c64 (&v)[16], const PhaseAConsts &k) {
+BRC_HD void inv_phaseA_lo(c64 (&v)[16]) {
     // level 0 (size 2, polynomials.cpp:113-122): plain sum / difference
 #pragma unroll
     for (int r = 0; r < 16; r += 2) inv_bf_one(v[r], v[r + 1]);
@@ -247,6 +287,8 @@ BRC_HD void inv_phaseA(c64 (&v)[16], const PhaseAConsts &k) {
         inv_bf_one(v[g], v[g + 2]);
         inv_bf_mi(v[g + 1], v[g + 3]);
     }
+}
+BRC_HD void inv_phaseA_hi(c64 (&v)[16], const PhaseAConsts &k) {
     // level 2 (size 8): table(8, j) = (1,0), (c4,c4), (-0,1), (-c4,c4)
 #pragma unroll
     for (int g = 0; g < 16; g += 8) {
@@ -265,68 +307,94 @@ BRC_HD void inv_phaseA(c64 (&v)[16], const PhaseAConsts &k) {
     inv_bf_neg(v[6], v[14], k.c4, k.c4);
     inv_bf_neg(v[7], v[15], k.c8, k.s8);
 }
-
-template <class TW>
-BRC_HD void inv_phaseB(c64 (&v)[16], int lane, const TW &tw) {
-    const int l3 = lane & 7;
-    // rho = (y6 y5 y4 | y3).  level 4 (size 32): pairs differ in y4 = rho bit1; j = y3<<3 | l3
-#pragma unroll
-    for (int y3 = 0; y3 < 2; y3++) {
-        const c64 w = tw(tw_idx(32, (y3 << 3) | l3));
-#pragma unroll
-        for (int hi = 0; hi < 4; hi++) {  // y6 y5
-            const int r0 = (hi << 2) | y3;
-            inv_bf(v[r0], v[r0 | 2], w);
-        }
-    }
-    // level 5 (size 64): pairs differ in y5 = rho bit2; j = y4<<4 | y3<<3 | l3
-#pragma unroll
-    for (int lo = 0; lo < 4; lo++) {  // y4 y3 = rho bits 1,0
-        const c64 w = tw(tw_idx(64, (lo << 3) | l3));
-#pragma unroll
-        for (int y6 = 0; y6 < 2; y6++) {
-            const int r0 = (y6 << 3) | lo;
-            inv_bf(v[r0], v[r0 | 4], w);
-        }
-    }
-    // level 6 (size 128): pairs differ in y6 = rho bit3; j = y5 y4 y3 l3
-#pragma unroll
-    for (int lo = 0; lo < 8; lo++) {
-        const c64 w = tw(tw_idx(128, (lo << 3) | l3));
-        inv_bf(v[lo], v[lo | 8], w);
-    }
+BRC_HD void inv_phaseA(c64 (&v)[16], const PhaseAConsts &k) {
+    inv_phaseA_lo(v);
+    inv_phaseA_hi(v, k);
 }
 
+// rho = (y6 y5 y4 | y3), l3 = lane & 7.
 template <class TW>
-BRC_HD void inv_phaseC(c64 (&v)[16], int lane, const TW &tw) {
-    // rho = (y9 y8 y7 | y3); lane = (y6 y5 y4 | y2 y1 y0); low 7 bits of y: lowj(y3) = (lane>>3)<<4 | y3<<3 | (lane&7)
-    const int base = ((lane >> 3) << 4) | (lane & 7);
-    // level 7 (size 256): pairs differ in y7 = rho bit1; j = y6..y0
+BRC_HD void inv_level4(c64 (&v)[16], const TW &tw) {
+    // size 32: pairs differ in y4 = rho bit1; j = y3<<3 | l3, and y3 = 1 is the quarter turn of y3 = 0
+    const c64 w = tw(TWS_IB + 0);
+#pragma unroll
+    for (int hi = 0; hi < 4; hi++) {  // y6 y5
+        inv_bf(v[hi << 2], v[(hi << 2) | 2], w);
+        inv_bf_q(v[(hi << 2) | 1], v[(hi << 2) | 3], w);
+    }
+}
+template <class TW>
+BRC_HD void inv_level5(c64 (&v)[16], const TW &tw) {
+    // size 64: pairs differ in y5 = rho bit2; j = y4<<4 | y3<<3 | l3; y4 = 1 is the quarter turn
 #pragma unroll
     for (int y3 = 0; y3 < 2; y3++) {
-        const c64 w = tw(tw_idx(256, base | (y3 << 3)));
+        const c64 w = tw(TWS_IB + 1 + y3);
+#pragma unroll
+        for (int y6 = 0; y6 < 2; y6++) {
+            inv_bf(v[(y6 << 3) | y3], v[(y6 << 3) | y3 | 4], w);
+            inv_bf_q(v[(y6 << 3) | 2 | y3], v[(y6 << 3) | 2 | y3 | 4], w);
+        }
+    }
+}
+template <class TW>
+BRC_HD void inv_level6(c64 (&v)[16], const TW &tw) {
+    // size 128: pairs differ in y6 = rho bit3; j = (y5 y4 y3)<<3 | l3; y5 = 1 is the quarter turn
+#pragma unroll
+    for (int lo = 0; lo < 4; lo++) {  // y4 y3
+        const c64 w = tw(TWS_IB + 3 + lo);
+        inv_bf(v[lo], v[lo | 8], w);
+        inv_bf_q(v[lo | 4], v[lo | 12], w);
+    }
+}
+template <class TW>
+BRC_HD void inv_phaseB(c64 (&v)[16], const TW &tw) {
+    inv_level4(v, tw);
+    inv_level5(v, tw);
+    inv_level6(v, tw);
+}
+
+// rho = (y9 y8 y7 | y3); lane = (y6 y5 y4 | y2 y1 y0); low 7 bits of y: (lane>>3)<<4 | y3<<3 | (lane&7)
+template <class TW>
+BRC_HD void inv_level7(c64 (&v)[16], const TW &tw) {
+    // size 256: pairs differ in y7 = rho bit1; j = y6..y0 (the quarter-turn bit y6 is a lane bit: no sharing)
+#pragma unroll
+    for (int y3 = 0; y3 < 2; y3++) {
+        const c64 w = tw(TWS_IC + y3);
 #pragma unroll
         for (int hi = 0; hi < 4; hi++) {
             const int r0 = (hi << 2) | y3;
             inv_bf(v[r0], v[r0 | 2], w);
         }
     }
-    // level 8 (size 512): pairs differ in y8 = rho bit2; j = y7<<7 | low7
+}
+template <class TW>
+BRC_HD void inv_level8(c64 (&v)[16], const TW &tw) {
+    // size 512: pairs differ in y8 = rho bit2; j = y7<<7 | low7; y7 = 1 is the quarter turn
 #pragma unroll
-    for (int lo = 0; lo < 4; lo++) {  // y7 y3
-        const c64 w = tw(tw_idx(512, ((lo >> 1) << 7) | base | ((lo & 1) << 3)));
+    for (int y3 = 0; y3 < 2; y3++) {
+        const c64 w = tw(TWS_IC + 2 + y3);
 #pragma unroll
         for (int y9 = 0; y9 < 2; y9++) {
-            const int r0 = (y9 << 3) | lo;
-            inv_bf(v[r0], v[r0 | 4], w);
+            inv_bf(v[(y9 << 3) | y3], v[(y9 << 3) | y3 | 4], w);
+            inv_bf_q(v[(y9 << 3) | 2 | y3], v[(y9 << 3) | 2 | y3 | 4], w);
         }
     }
-    // level 9 (size 1024): pairs differ in y9 = rho bit3; j = y8 y7<<7 | low7
+}
+template <class TW>
+BRC_HD void inv_level9(c64 (&v)[16], const TW &tw) {
+    // size 1024: pairs differ in y9 = rho bit3; j = (y8 y7)<<7 | low7; y8 = 1 is the quarter turn
 #pragma unroll
-    for (int lo = 0; lo < 8; lo++) {  // y8 y7 y3
-        const c64 w = tw(tw_idx(1024, ((lo >> 1) << 7) | base | ((lo & 1) << 3)));
+    for (int lo = 0; lo < 4; lo++) {  // y7 y3
+        const c64 w = tw(TWS_IC + 4 + lo);
         inv_bf(v[lo], v[lo | 8], w);
+        inv_bf_q(v[lo | 4], v[lo | 12], w);
     }
+}
+template <class TW>
+BRC_HD void inv_phaseC(c64 (&v)[16], const TW &tw) {
+    inv_level7(v, tw);
+    inv_level8(v, tw);
+    inv_level9(v, tw);
 }
 
 // last merge (size 2048) + scaling + truncation: polynomials.cpp:160-166 with E = 0, then :392.
@@ -340,15 +408,20 @@ BRC_HD int32_t trunc_to_torus32_bounded(double x) {
     __builtin_memcpy(&u, &t, 8);
     return (int32_t) (uint32_t) u;
 }
+template <bool BOUNDED>
+BRC_HD int32_t scale_to_torus32(double tr) {
+    const double scaled = tr * 4194304.0;  // (tr * 2^-10) * 2^32, both exact scalings
+    return BOUNDED ? trunc_to_torus32_bounded(scaled) : (int32_t) (uint32_t) (uint64_t) (int64_t) scaled;
+}
+// output rho of lane l is coefficient y = inv_yC(l, rho); twiddle table(2048, y); rho >= 8 (y9 = 1) is the quarter
+// turn of rho - 8:  Wr*(-s) + Wi*c = Wi*c - Wr*s exactly
 template <bool BOUNDED, class TW>
-BRC_HD void inv_final(int32_t (&out)[16], const c64 (&v)[16], int lane, const TW &tw) {
+BRC_HD void inv_final(int32_t (&out)[16], const c64 (&v)[16], const TW &tw) {
 #pragma unroll
-    for (int rho = 0; rho < 16; rho++) {
-        const int y = inv_yC(lane, rho);
-        const c64 w = tw(tw_idx(2048, y));
-        const double tr = v[rho].re * w.re + v[rho].im * w.im;
-        const double scaled = tr * 4194304.0;  // (tr * 2^-10) * 2^32, both exact scalings
-        out[rho] = BOUNDED ? trunc_to_torus32_bounded(scaled) : (int32_t) (uint32_t) (uint64_t) (int64_t) scaled;
+    for (int rho = 0; rho < 8; rho++) {
+        const c64 w = tw(TWS_FIN + rho);
+        out[rho] = scale_to_torus32<BOUNDED>(v[rho].re * w.re + v[rho].im * w.im);
+        out[rho + 8] = scale_to_torus32<BOUNDED>(v[rho + 8].im * w.re - v[rho + 8].re * w.im);
     }
 }
 

@@ -13,6 +13,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the arithmetic contract of br_core.h forbids FMA
 // contraction).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -37,9 +38,9 @@ constexpr int kKsT = 8, kKsBasebit = 2;
 // ---------------------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------------------
-struct TwLds {  // lane-dependent indices: read from the LDS copy of the table
-    const c64 *t;
-    __device__ __forceinline__ c64 operator()(int i) const { return t[i]; }
+struct TwLds {  // this lane's column of the per-lane twiddle image in LDS (br_core.h: tw_slot_index)
+    const c64 *t;  // image + lane
+    __device__ __forceinline__ c64 operator()(int slot) const { return t[slot * 64]; }
 };
 
 // Exchanges between lanes of ONE wave go through LDS without a workgroup barrier: LDS operations of a wave are
@@ -57,14 +58,14 @@ __device__ __forceinline__ void wave_fwd(c64 (&v)[8], int lane, c64 *scratch, co
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xB(lane, r))];
     wave_sync();
-    fwd_phaseB(v, lane, twl);
+    fwd_phaseB(v, twl);
 #pragma unroll
     for (int r = 0; r < 8; r++) scratch[swz(fwd_xB(lane, r))] = v[r];
     wave_sync();
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xC(lane, r))];
     wave_sync();
-    fwd_phaseC(v, lane, twl);
+    fwd_phaseC(v, twl);
 }
 
 // element index inside one half (fixed y3) of the 1024-entry inverse working array
@@ -85,7 +86,7 @@ __device__ __forceinline__ void wave_inv(int32_t (&out)[16], c64 (&v)[16], int l
         for (int q = 0; q < 8; q++) w[(q << 1) | h] = scratch[swz(inv_elem(inv_yB(lane, (q << 1) | h)))];
         wave_sync();
     }
-    inv_phaseB(w, lane, twl);
+    inv_phaseB(w, twl);
     // layout B -> layout C (regs y9y8y7,y3)
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -96,8 +97,8 @@ __device__ __forceinline__ void wave_inv(int32_t (&out)[16], c64 (&v)[16], int l
         for (int q = 0; q < 8; q++) v[(q << 1) | h] = scratch[swz(inv_elem(inv_yC(lane, (q << 1) | h)))];
         wave_sync();
     }
-    inv_phaseC(v, lane, twl);
-    inv_final<BOUNDED>(out, v, lane, twl);
+    inv_phaseC(v, twl);
+    inv_final<BOUNDED>(out, v, twl);
 }
 
 // spectrum held as (lane, r) <-> physical slot x = r<<6|lane  ->  inverse-transform input registers, via scratch
@@ -126,7 +127,7 @@ __device__ __forceinline__ void cmac(c64 &acc, const c64 a, const c64 b) {
 }
 
 __device__ __forceinline__ void load_tw_to_lds(c64 *tw_lds, const c64 *tw) {
-    for (int i = threadIdx.x; i < kTwEntries; i += blockDim.x) tw_lds[i] = tw[i];
+    for (int i = threadIdx.x; i < kTwLaneEntries; i += blockDim.x) tw_lds[i] = tw[i];
     __syncthreads();
 }
 
@@ -151,9 +152,12 @@ struct BrArgs {
     int32_t *acc_io;       // MODE_RAW / MODE_EXTMUL: TLWE accumulators [B][2][N], in/out
     const int32_t *bara;   // MODE_RAW: [B][n] rotation amounts; MODE_EXTMUL: [B] key index
     const c64 *bk;         // [n][6][2][8][64] physical slot order
-    const c64 *tw;         // twiddle table, kTwEntries
+    const c64 *tw;         // per-lane twiddle image, kTwLaneEntries
     PhaseAConsts ka;       // in-register-phase twiddles (scalar registers)
     long long B;
+#ifdef TFHE_HIP_CLOCK_DIAG  // diagnostic build only (tools/clock_diag.sh): per-wave (shader cycles, 100 MHz ticks)
+    unsigned long long *diag;
+#endif
 };
 enum { MODE_GATE = 0, MODE_RAW = 1, MODE_EXTMUL = 2 };
 
@@ -164,6 +168,202 @@ constexpr int kBrLdsPerWave = 2 * kN * 4 + kNh * 16;  // accumulator + scratch =
 //     = tLweMulByXaiMinusOne (tlwe-functions.cpp:202)  ->  tGswFFTExternMulToTLwe (tgsw-fft-operations.cpp:92-120)
 //       -> tLweAddTo (tlwe-functions.cpp:149)
 // EXTMUL variant: ACC <- bk_i (*) ACC (the external product alone).
+//
+// Schedule.  A lone wave spends ~40 % of a CMux waiting for its own LDS transposes (write -> read of the same scratch),
+// and two waves per SIMD do not hide all of it.  So every write->read gap is filled with independent arithmetic of the
+// same wave:  forward transform t carries the multiply-accumulate of transform t-1 in its two gaps (one key column
+// each, followed by the request for the same column of row t, which then has a whole transform to arrive), and the two
+// inverse transforms run staggered by one level group, each one's transposes covered by the other's butterflies.
+// Order of the floating-point operations per accumulator is unchanged (rows p = 0..5 in order): results identical.
+#ifndef TFHE_HIP_CMUX_V1
+__device__ __forceinline__ void mac_col(c64 (&acc)[8], const c64 (&v)[8], const c64 (&kb)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) cmac(acc[r], v[r], kb[r]);
+}
+__device__ __forceinline__ void load_col(c64 (&kb)[8], const c64 *row) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) kb[r] = row[r * 64];
+}
+// halves (h = fixed y3) of the inverse transposes through the 8 KB scratch
+template <int H>
+__device__ __forceinline__ void inv_t1_write(c64 *scratch, const c64 (&v)[16], int lane) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) scratch[swz(inv_elem(inv_yA(lane, (H << 3) | q)))] = v[(H << 3) | q];
+}
+template <int H>
+__device__ __forceinline__ void inv_t1_read(c64 (&w)[16], const c64 *scratch, int lane) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) w[(q << 1) | H] = scratch[swz(inv_elem(inv_yB(lane, (q << 1) | H)))];
+}
+template <int H>
+__device__ __forceinline__ void inv_t2_write(c64 *scratch, const c64 (&w)[16], int lane) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) scratch[swz(inv_elem(inv_yB(lane, (q << 1) | H)))] = w[(q << 1) | H];
+}
+template <int H>
+__device__ __forceinline__ void inv_t2_read(c64 (&v)[16], const c64 *scratch, int lane) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[(q << 1) | H] = scratch[swz(inv_elem(inv_yC(lane, (q << 1) | H)))];
+}
+__device__ __forceinline__ void spec_write(c64 *scratch, const c64 (&s)[8], int lane) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) scratch[swz(fwd_xC(lane, r))] = s[r];
+}
+__device__ __forceinline__ void spec_read(c64 (&v)[16], const c64 *scratch, int lane) {
+#pragma unroll
+    for (int rho = 0; rho < 16; rho++) {
+        const int m = (br4(rho) << 6) | lane;
+        if (br4(rho) < 8) {
+            v[rho] = scratch[swz(gray(m))];
+        } else {
+            const c64 t = scratch[swz(gray(1023 - m))];
+            v[rho] = {t.re, -t.im};
+        }
+    }
+}
+
+// forward transform t (row c*l+p = t) of one CMux with the MAC of transform t-1 in its transpose gaps
+template <bool ROTATE>
+__device__ __forceinline__ void fwd_step(const int t, c64 (&v)[8], const c64 (&pv)[8], c64 (&tmpa)[2][8],
+                                         c64 (&kb)[8], uint32_t (&tlo)[8], uint32_t (&thi)[8], const int32_t *acc,
+                                         c64 *scratch, int lane, int bara, const c64 *bki, const PhaseAConsts &twu,
+                                         const TwLds &twl) {
+    const int c = t >= kL ? 1 : 0, p = t - c * kL;
+    if (p == 0) {  // rotated differences of column c, offset added and digit sign bits flipped (decomp_prepare)
+        const int32_t *accc = acc + c * kN;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int j = (br3(r) << 6) | lane;
+            if (ROTATE) {
+                tlo[r] = decomp_prepare(rot_minus_one(accc, bara, j));
+                thi[r] = decomp_prepare(rot_minus_one(accc, bara, j + kNh));
+            } else {
+                tlo[r] = decomp_prepare(accc[j]);
+                thi[r] = decomp_prepare(accc[j + kNh]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = {(double) decomp_digit(tlo[r], p), (double) decomp_digit(thi[r], p)};
+    // one 8-value key buffer in rotation: holds (row t-1, column 0) on entry, (row t-1, column 1) between the two
+    // gaps, (row t, column 0) on exit
+    const c64 *row = bki + (size_t) (t * 2) * kNh + lane;
+    fwd_phaseA(v, twu);
+#pragma unroll
+    for (int r = 0; r < 8; r++) scratch[swz(fwd_xA(lane, r))] = v[r];
+    wave_sync();
+    if (t > 0) {
+        mac_col(tmpa[0], pv, kb);
+        load_col(kb, row - kNh);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xB(lane, r))];
+    wave_sync();
+    fwd_phaseB(v, twl);
+#pragma unroll
+    for (int r = 0; r < 8; r++) scratch[swz(fwd_xB(lane, r))] = v[r];
+    wave_sync();
+    if (t > 0) mac_col(tmpa[1], pv, kb);
+    load_col(kb, row);
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xC(lane, r))];
+    wave_sync();
+    fwd_phaseC(v, twl);
+}
+
+template <bool ROTATE>
+__device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int bara, const c64 *bki,
+                                     const PhaseAConsts &twu, const TwLds &twl) {
+    c64 tmpa[2][8], kb[8], va[8], vb[8];
+    uint32_t tlo[8], thi[8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) tmpa[c][r] = {0.0, 0.0};
+#pragma unroll 1
+    for (int t = 0; t < 2 * kL; t += 2) {
+        fwd_step<ROTATE>(t, va, vb, tmpa, kb, tlo, thi, acc, scratch, lane, bara, bki, twu, twl);
+        fwd_step<ROTATE>(t + 1, vb, va, tmpa, kb, tlo, thi, acc, scratch, lane, bara, bki, twu, twl);
+    }
+    // tail of the forward pipeline and the two inverse transforms A (column 0) and B (column 1), staggered
+    c64 xa[16], xb[16], wa[16], wb[16];
+    mac_col(tmpa[0], vb, kb);
+    load_col(kb, bki + (size_t) (2 * kKpl - 1) * kNh + lane);
+    spec_write(scratch, tmpa[0], lane);
+    wave_sync();
+    spec_read(xa, scratch, lane);
+    mac_col(tmpa[1], vb, kb);
+    wave_sync();
+    spec_write(scratch, tmpa[1], lane);
+    wave_sync();
+    inv_phaseA(xa, twu);
+    spec_read(xb, scratch, lane);
+    wave_sync();
+    inv_t1_write<0>(scratch, xa, lane);
+    wave_sync();
+    inv_phaseA_lo(xb);
+    inv_t1_read<0>(wa, scratch, lane);
+    wave_sync();
+    inv_t1_write<1>(scratch, xa, lane);
+    wave_sync();
+    inv_phaseA_hi(xb, twu);
+    inv_t1_read<1>(wa, scratch, lane);
+    wave_sync();
+    inv_t1_write<0>(scratch, xb, lane);
+    wave_sync();
+    inv_level4(wa, twl);
+    inv_t1_read<0>(wb, scratch, lane);
+    wave_sync();
+    inv_t1_write<1>(scratch, xb, lane);
+    wave_sync();
+    inv_level5(wa, twl);
+    inv_t1_read<1>(wb, scratch, lane);
+    wave_sync();
+    inv_level6(wa, twl);
+    inv_t2_write<0>(scratch, wa, lane);
+    wave_sync();
+    inv_level4(wb, twl);
+    inv_t2_read<0>(xa, scratch, lane);
+    wave_sync();
+    inv_t2_write<1>(scratch, wa, lane);
+    wave_sync();
+    inv_level5(wb, twl);
+    inv_t2_read<1>(xa, scratch, lane);
+    wave_sync();
+    inv_level6(wb, twl);
+    inv_t2_write<0>(scratch, wb, lane);
+    wave_sync();
+    inv_level7(xa, twl);
+    inv_t2_read<0>(xb, scratch, lane);
+    wave_sync();
+    inv_t2_write<1>(scratch, wb, lane);
+    wave_sync();
+    inv_level8(xa, twl);
+    inv_t2_read<1>(xb, scratch, lane);
+    wave_sync();
+    inv_level9(xa, twl);
+    {
+        int32_t res[16];
+        inv_final<true>(res, xa, twl);
+#pragma unroll
+        for (int rho = 0; rho < 16; rho++) {
+            const int y = inv_yC(lane, rho);
+            acc[y] = ROTATE ? (int32_t) ((uint32_t) acc[y] + (uint32_t) res[rho]) : res[rho];
+        }
+    }
+    inv_phaseC(xb, twl);
+    {
+        int32_t res[16];
+        inv_final<true>(res, xb, twl);
+#pragma unroll
+        for (int rho = 0; rho < 16; rho++) {
+            const int y = inv_yC(lane, rho);
+            acc[kN + y] = ROTATE ? (int32_t) ((uint32_t) acc[kN + y] + (uint32_t) res[rho]) : res[rho];
+        }
+    }
+    wave_sync();
+}
+#else
 template <bool ROTATE>
 __device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int bara, const c64 *bki,
                                      const PhaseAConsts &twu, const TwLds &twl) {
@@ -226,6 +426,8 @@ __device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int b
     wave_sync();
 }
 
+#endif
+
 template <int MODE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -233,13 +435,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
     load_tw_to_lds(tw_lds, A.tw);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    unsigned char *mine = lds_raw + kTwEntries * sizeof(c64) + (size_t) wave * kBrLdsPerWave;
+    unsigned char *mine = lds_raw + kTwLaneEntries * sizeof(c64) + (size_t) wave * kBrLdsPerWave;
     int32_t *acc = reinterpret_cast<int32_t *>(mine);
     c64 *scratch = reinterpret_cast<c64 *>(mine + 2 * kN * 4);
     const long long g = (long long) blockIdx.x * WAVES + wave;
     if (g >= A.B) return;  // wave-uniform; no workgroup barrier after this point
     const PhaseAConsts twu = A.ka;
-    const TwLds twl{tw_lds};
+    const TwLds twl{tw_lds + lane};
 
     if (MODE == MODE_GATE) {
         // tfhe_bootstrap_woKS_FFT (lwe-bootstrapping-functions-fft.cpp:222-253) with the gate's linear
@@ -270,12 +472,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
             acc[kN + j] = ((j + barb) & kN) ? (int32_t) (0u - (uint32_t) A.mu) : A.mu;
         }
         wave_sync();
+#ifdef TFHE_HIP_CLOCK_DIAG
+        const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll 1
         for (int i = 0; i < kLwe; i++) {
             const int bara = __builtin_amdgcn_readfirstlane(modswitch_2N(comb(i)));
             if (bara == 0) continue;  // lwe-bootstrapping-functions-fft.cpp:154
             cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
         }
+#ifdef TFHE_HIP_CLOCK_DIAG
+        if (A.diag && lane == 0) {
+            A.diag[2 * g] = __builtin_amdgcn_s_memtime() - diag_t0;
+            A.diag[2 * g + 1] = __builtin_amdgcn_s_memrealtime() - diag_r0;
+        }
+#endif
         // tLweExtractLweSampleIndex(index 0), lwe.cpp:41-53
         int32_t *o = A.out + g * kExt;
 #pragma unroll
@@ -549,7 +760,7 @@ __global__ __launch_bounds__(256) void k_bk_convert(const int32_t *__restrict__ 
     c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
     load_tw_to_lds(tw_lds, tw);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwEntries * sizeof(c64)) + wave * kNh;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwLaneEntries * sizeof(c64)) + wave * kNh;
     const int poly = blockIdx.x * 4 + wave;
     if (poly >= npoly) return;
     const int32_t *p = coef + (size_t) poly * kN;
@@ -560,7 +771,7 @@ __global__ __launch_bounds__(256) void k_bk_convert(const int32_t *__restrict__ 
         const int j = (br3(r) << 6) | lane;
         v[r] = {p[j] * s, p[j + kNh] * s};
     }
-    wave_fwd(v, lane, scratch, ka, TwLds{tw_lds});
+    wave_fwd(v, lane, scratch, ka, TwLds{tw_lds + lane});
 #pragma unroll
     for (int r = 0; r < 8; r++) bk[(size_t) poly * kNh + r * 64 + lane] = v[r];
 }
@@ -594,7 +805,7 @@ __global__ __launch_bounds__(256) void k_poly_fwd(const int32_t *__restrict__ po
     c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
     load_tw_to_lds(tw_lds, tw);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwEntries * sizeof(c64)) + wave * kNh;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwLaneEntries * sizeof(c64)) + wave * kNh;
     const long long poly = (long long) blockIdx.x * 4 + wave;
     if (poly >= count) return;
     const int32_t *p = polys + poly * kN;
@@ -605,7 +816,7 @@ __global__ __launch_bounds__(256) void k_poly_fwd(const int32_t *__restrict__ po
         const int j = (br3(r) << 6) | lane;
         v[r] = {p[j] * s, p[j + kNh] * s};
     }
-    wave_fwd(v, lane, scratch, ka, TwLds{tw_lds});
+    wave_fwd(v, lane, scratch, ka, TwLds{tw_lds + lane});
 #pragma unroll
     for (int r = 0; r < 8; r++) spectra[poly * kNh + igray(fwd_xC(lane, r))] = v[r];
 }
@@ -616,7 +827,7 @@ __global__ __launch_bounds__(256) void k_poly_inv(const c64 *__restrict__ spectr
     c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
     load_tw_to_lds(tw_lds, tw);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwEntries * sizeof(c64)) + wave * kNh;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwLaneEntries * sizeof(c64)) + wave * kNh;
     const long long poly = (long long) blockIdx.x * 4 + wave;
     if (poly >= count) return;
     const c64 *C = spectra + poly * kNh;
@@ -631,7 +842,7 @@ __global__ __launch_bounds__(256) void k_poly_inv(const c64 *__restrict__ spectr
         }
     }
     int32_t res[16];
-    wave_inv<false>(res, v, lane, scratch, ka, TwLds{tw_lds});
+    wave_inv<false>(res, v, lane, scratch, ka, TwLds{tw_lds + lane});
 #pragma unroll
     for (int rho = 0; rho < 16; rho++) polys[poly * kN + inv_yC(lane, rho)] = res[rho];
 }
@@ -643,11 +854,11 @@ __global__ __launch_bounds__(256) void k_poly_mul(const int32_t *__restrict__ ip
     c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
     load_tw_to_lds(tw_lds, tw);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwEntries * sizeof(c64)) + wave * kNh;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwLaneEntries * sizeof(c64)) + wave * kNh;
     const long long poly = (long long) blockIdx.x * 4 + wave;
     if (poly >= count) return;
     const PhaseAConsts twu = ka;
-    const TwLds twl{tw_lds};
+    const TwLds twl{tw_lds + lane};
     c64 a[8], b[8], prod[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -770,13 +981,40 @@ namespace {
 constexpr size_t kBkBytes = (size_t) kLwe * kKpl * 2 * kNh * sizeof(c64);
 constexpr size_t kKsDevBytes = (size_t) kN * kKsT * 3 * kKsRow * sizeof(int32_t);
 constexpr size_t kKsHostElems = (size_t) kN * kKsT * 4 * kCt;
-constexpr int kFftLds = kTwEntries * (int) sizeof(c64) + 4 * kNh * (int) sizeof(c64);
+constexpr int kFftLds = kTwLaneEntries * (int) sizeof(c64) + 4 * kNh * (int) sizeof(c64);
 
 template <int MODE>
-int launch_br(tfhe_hip_ctx *c, const BrArgs &A) {
-    if (A.B <= 0) return TFHE_HIP_OK;
+int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
+    if (A0.B <= 0) return TFHE_HIP_OK;
+    BrArgs A = A0;
+#ifdef TFHE_HIP_CLOCK_DIAG
+    static unsigned long long *d_diag = nullptr;
+    static long long diag_cap = 0;
+    if (A.B > diag_cap) {
+        if (d_diag) (void) hipFree(d_diag);
+        HIPCHK(hipMalloc((void **) &d_diag, (size_t) A.B * 16));
+        diag_cap = A.B;
+    }
+    HIPCHK(hipMemsetAsync(d_diag, 0, (size_t) A.B * 16, c->stream));
+    A.diag = d_diag;
+    struct DiagPrint {
+        tfhe_hip_ctx *c; long long B; unsigned long long *d;
+        ~DiagPrint() {
+            std::vector<unsigned long long> h(2 * B);
+            (void) hipStreamSynchronize(c->stream);
+            (void) hipMemcpy(h.data(), d, (size_t) B * 16, hipMemcpyDeviceToHost);
+            std::vector<double> ghz, cyc;
+            for (long long i = 0; i < B; i++)
+                if (h[2 * i + 1]) { ghz.push_back(0.1 * (double) h[2 * i] / (double) h[2 * i + 1]); cyc.push_back((double) h[2 * i]); }
+            if (ghz.empty()) return;
+            std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+            fprintf(stderr, "[clock diag] B=%lld in-kernel clock median %.3f GHz (min %.3f max %.3f); loop cycles per wave median %.0f\n",
+                    B, ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2]);
+        }
+    } diag_print{c, A.B, d_diag};
+#endif
     const int waves = c->br_waves;
-    const size_t lds = kTwEntries * sizeof(c64) + (size_t) waves * kBrLdsPerWave;
+    const size_t lds = kTwLaneEntries * sizeof(c64) + (size_t) waves * kBrLdsPerWave;
     const unsigned grid = (unsigned) ((A.B + waves - 1) / waves);
     if (waves == 8) {
         HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate<MODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -876,8 +1114,10 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     const char *km = getenv("TFHE_HIP_KS_MFMA");
     if (km) c->ks_mfma = atoi(km) != 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **) &c->tw, kTwEntries * sizeof(c64));
-    if (e == hipSuccess) e = hipMemcpy(c->tw, tw.data(), kTwEntries * sizeof(c64), hipMemcpyHostToDevice);
+    std::vector<c64> image(kTwLaneEntries);
+    build_lane_twiddles(image.data(), [&](int i) { return tw[i]; });
+    if (e == hipSuccess) e = hipMalloc((void **) &c->tw, kTwLaneEntries * sizeof(c64));
+    if (e == hipSuccess) e = hipMemcpy(c->tw, image.data(), kTwLaneEntries * sizeof(c64), hipMemcpyHostToDevice);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e != hipSuccess) {
         tfhe_hip_destroy(c);
