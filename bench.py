@@ -74,6 +74,8 @@ def side_bench(args, torch, dev, rank, world):
     from tfhe_amd import Client, Engine, Gate, PARAMS as PR
     assert world == 1, "side benches are single-GPU"
     eng = Engine(0)
+    if args.workload == "adder":
+        return adder_bench(args, torch, dev, eng)
     if args.workload == "mux":
         client = Client()
         keys = client.keygen(42)
@@ -111,6 +113,62 @@ def side_bench(args, torch, dev, rank, world):
     eng.close()
 
 
+def adder_bench(args, torch, dev, eng):
+    """BASELINE configs[3]: W independent 32-bit ripple-carry adders, the reference's full_adder_MUX gate sequence
+    (src/test/test-addition-boot.cpp:30-67), levelized; every level is one call on a device-resident ciphertext pool
+    (tfhe_hip_gate_level_dev).  The reference evaluates the same circuit as 32 x 4 sequential gate calls."""
+    from tfhe_amd import Client, Gate, PARAMS as PR
+    from tfhe_amd.netlist import Netlist, full_adder_mux
+    W, nbits = args.instances, 32
+    nl = Netlist()
+    x, y = nl.input("x", nbits), nl.input("y", nbits)
+    nl.output("out", full_adder_mux(nl, x, y))
+    client = Client()
+    keys = client.keygen(42)
+    eng.load_keys_coef(keys.bk_coef, keys.ks)
+    rng = np.random.default_rng(9)
+    xs = rng.integers(0, 1 << nbits, W, dtype=np.int64)
+    ys = rng.integers(0, 1 << nbits, W, dtype=np.int64)
+    shifts = np.arange(nbits)
+    xb = ((xs[:, None] >> shifts) & 1).astype(np.uint8).reshape(-1)
+    yb = ((ys[:, None] >> shifts) & 1).astype(np.uint8).reshape(-1)
+    rows = W * nl.n_wires
+    pool = torch.zeros((rows, PR.n + 1), dtype=torch.int32, device=dev)
+    base = (np.arange(W) * nl.n_wires)[:, None]
+    pool[torch.from_numpy((base + np.array(x)[None, :]).reshape(-1)).to(dev)] = \
+        torch.from_numpy(client.encrypt(keys, xb, seed=71)).to(dev)
+    pool[torch.from_numpy((base + np.array(y)[None, :]).reshape(-1)).to(dev)] = \
+        torch.from_numpy(client.encrypt(keys, yb, seed=72)).to(dev)
+    levels = nl.level_arrays(instances=W)
+    ngates = sum(int((lv[:, 0] <= int(Gate.MUX)).sum()) for lv in levels)
+    nboot = sum(int((lv[:, 0] < int(Gate.MUX)).sum()) + 2 * int((lv[:, 0] == int(Gate.MUX)).sum()) for lv in levels)
+
+    def run():
+        for lv in levels:
+            eng.gate_level_dev(pool, rows, lv)
+
+    for _ in range(args.warmup):
+        run()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    eng.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    out_rows = torch.from_numpy((base + np.array(nl.outputs["out"])[None, :]).reshape(-1)).to(dev)
+    bits, _ = client.decrypt(keys, pool[out_rows].cpu().numpy())
+    got = (bits.reshape(W, nbits + 1).astype(np.int64) << np.arange(nbits + 1)).sum(axis=1)
+    assert np.array_equal(got, xs + ys), "adder outputs decrypt wrongly"
+    print(json.dumps({"metric": "bootstrapped gates/sec, levelized 32-bit adders (full_adder_MUX netlist)",
+                      "value": ngates / dt, "unit": "gates/s", "n_gpus": 1, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "f64",
+                      "data": "synthetic",
+                      "config": {"workload": "adder", "instances": W, "bits": nbits, "levels": len(levels),
+                                 "gates_per_step": ngates, "bootstraps_per_step": nboot,
+                                 "additions_per_s": W / dt, "sums_decrypt_correctly": True}}), flush=True)
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,8 +176,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=16384, help="gates per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="nand", choices=["nand", "mux", "fft"],
-                    help="nand: BASELINE configs[1] (default, the headline); mux / fft: BASELINE configs[4] side benches")
+    ap.add_argument("--workload", default="nand", choices=["nand", "mux", "fft", "adder"],
+                    help="nand: BASELINE configs[1] (default, the headline); adder: configs[3] levelized 32-bit adders; "
+                         "mux / fft: configs[4] side benches")
+    ap.add_argument("--instances", type=int, default=4096, help="adder workload: independent adder instances")
     args = ap.parse_args()
 
     import torch
