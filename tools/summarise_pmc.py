@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
 names = {"k_blind_rotate": "blind_rotate", "k_keyswitch_mfma": "keyswitch_mfma", "k_ks_transpose": "ks_transpose"}
 out = collections.defaultdict(dict)
-for p in ("fetch", "write", "sq1", "sq2"):
+for p in ("fetch", "write", "sq1", "sq2", "tcc"):
     files = glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s" % (tag, p), "*", "*_counter_collection.csv"))
     if not files:
         continue
