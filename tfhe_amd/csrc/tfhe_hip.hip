@@ -175,7 +175,6 @@ constexpr int kBrLdsPerWave = 2 * kN * 4 + kNh * 16;  // accumulator + scratch =
 // each, followed by the request for the same column of row t, which then has a whole transform to arrive), and the two
 // inverse transforms run staggered by one level group, each one's transposes covered by the other's butterflies.
 // Order of the floating-point operations per accumulator is unchanged (rows p = 0..5 in order): results identical.
-#ifndef TFHE_HIP_CMUX_V1
 __device__ __forceinline__ void mac_col(c64 (&acc)[8], const c64 (&v)[8], const c64 (&kb)[8]) {
 #pragma unroll
     for (int r = 0; r < 8; r++) cmac(acc[r], v[r], kb[r]);
@@ -363,70 +362,6 @@ __device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int b
     }
     wave_sync();
 }
-#else
-template <bool ROTATE>
-__device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int bara, const c64 *bki,
-                                     const PhaseAConsts &twu, const TwLds &twl) {
-    c64 tmpa[2][8];
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int r = 0; r < 8; r++) tmpa[c][r] = {0.0, 0.0};
-
-#pragma unroll 1
-    for (int c = 0; c < 2; c++) {
-        uint32_t tlo[8], thi[8];  // rotated differences, offset added and digit sign bits flipped (decomp_prepare)
-        const int32_t *accc = acc + c * kN;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int j = (br3(r) << 6) | lane;
-            if (ROTATE) {
-                tlo[r] = decomp_prepare(rot_minus_one(accc, bara, j));
-                thi[r] = decomp_prepare(rot_minus_one(accc, bara, j + kNh));
-            } else {
-                tlo[r] = decomp_prepare(accc[j]);
-                thi[r] = decomp_prepare(accc[j + kNh]);
-            }
-        }
-#pragma unroll 1
-        for (int p = 0; p < kL; p++) {
-            // key row (c,p): 2 x 512 spectrum values, 16 x 16 B per lane, requested before the transform so that the
-            // L2/HBM latency hides behind it
-            const c64 *row = bki + (size_t) ((c * kL + p) * 2) * kNh + lane;
-            c64 kb[2][8];
-#pragma unroll
-            for (int c2 = 0; c2 < 2; c2++)
-#pragma unroll
-                for (int r = 0; r < 8; r++) kb[c2][r] = row[c2 * kNh + r * 64];
-            c64 v[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++)
-                v[r] = {(double) decomp_digit(tlo[r], p), (double) decomp_digit(thi[r], p)};
-            wave_fwd(v, lane, scratch, twu, twl);
-#pragma unroll
-            for (int c2 = 0; c2 < 2; c2++)
-#pragma unroll
-                for (int r = 0; r < 8; r++) cmac(tmpa[c2][r], v[r], kb[c2][r]);
-        }
-    }
-#pragma unroll 1
-    for (int c2 = 0; c2 < 2; c2++) {
-        c64 v[16];
-        int32_t res[16];
-        if (c2 == 0) spectrum_to_inv_input(v, tmpa[0], lane, scratch);
-        else spectrum_to_inv_input(v, tmpa[1], lane, scratch);
-        wave_inv<true>(res, v, lane, scratch, twu, twl);
-        int32_t *accc = acc + c2 * kN;
-#pragma unroll
-        for (int rho = 0; rho < 16; rho++) {
-            const int y = inv_yC(lane, rho);
-            accc[y] = ROTATE ? (int32_t) ((uint32_t) accc[y] + (uint32_t) res[rho]) : res[rho];
-        }
-    }
-    wave_sync();
-}
-
-#endif
 
 template <int MODE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
@@ -973,7 +908,7 @@ struct tfhe_hip_ctx {
     std::vector<uint8_t> h_mark;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // br start/stop, ks start/stop
     bool ev_br = false, ev_ks = false;
-    int br_waves = 8;
+    int br_waves = 0;  // 0 = by batch size; TFHE_HIP_BR_WAVES=1|4|8 forces a shape
 };
 
 namespace {
@@ -1013,18 +948,22 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
         }
     } diag_print{c, A.B, d_diag};
 #endif
-    const int waves = c->br_waves;
+    // waves per workgroup: 8 (two per SIMD) is the throughput shape.  Batches that cannot fill the chip that way run
+    // with fewer waves per CU, which finish sooner (measured per wave: 8 per CU 16.4 ms, 4 per CU 10.5 ms, alone 8.8 ms)
+    int waves = c->br_waves;
+    if (waves == 0) waves = A.B <= 256 ? 1 : A.B <= 1024 ? 4 : 8;
     const size_t lds = kTwLaneEntries * sizeof(c64) + (size_t) waves * kBrLdsPerWave;
     const unsigned grid = (unsigned) ((A.B + waves - 1) / waves);
-    if (waves == 8) {
-        HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate<MODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int) lds));
-        hipLaunchKernelGGL((k_blind_rotate<MODE, 8>), dim3(grid), dim3(512), lds, c->stream, A);
-    } else {
-        HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate<MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int) lds));
-        hipLaunchKernelGGL((k_blind_rotate<MODE, 4>), dim3(grid), dim3(256), lds, c->stream, A);
-    }
+    auto go = [&](auto kernel) -> int {
+        HIPCHK(hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * waves), lds, c->stream, A);
+        return TFHE_HIP_OK;
+    };
+    int r;
+    if (waves == 8) r = go(k_blind_rotate<MODE, 8>);
+    else if (waves == 4) r = go(k_blind_rotate<MODE, 4>);
+    else r = go(k_blind_rotate<MODE, 1>);
+    if (r) return r;
     HIPCHK(hipGetLastError());
     return TFHE_HIP_OK;
 }
@@ -1109,8 +1048,7 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     c->device = device;
     c->ka = make_phaseA_consts([&](int i) { return tw[i]; });
     const char *w = getenv("TFHE_HIP_BR_WAVES");
-    if (w && atoi(w) == 8) c->br_waves = 8;
-    if (w && atoi(w) == 4) c->br_waves = 4;
+    if (w && (atoi(w) == 8 || atoi(w) == 4 || atoi(w) == 1)) c->br_waves = atoi(w);
     const char *km = getenv("TFHE_HIP_KS_MFMA");
     if (km) c->ks_mfma = atoi(km) != 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
