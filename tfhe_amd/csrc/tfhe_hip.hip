@@ -43,6 +43,22 @@ struct TwLds {  // this lane's column of the per-lane twiddle image in LDS (br_c
     __device__ __forceinline__ c64 operator()(int slot) const { return t[slot * 64]; }
 };
 
+// twiddles fetched ahead of the level that uses them
+template <int N>
+struct TwPre {
+    c64 w[N];
+};
+template <int N, int BASE>
+struct TwView {
+    const TwPre<N> &p;
+    __device__ __forceinline__ c64 operator()(int slot) const { return p.w[slot - BASE]; }
+};
+template <int N>
+__device__ __forceinline__ void tw_preload(TwPre<N> &p, const TwLds &twl, int base) {
+#pragma unroll
+    for (int i = 0; i < N; i++) p.w[i] = twl(base + i);
+}
+
 // Exchanges between lanes of ONE wave go through LDS without a workgroup barrier: LDS operations of a wave are
 // executed in issue order, so only the compiler has to be kept from reordering them.
 __device__ __forceinline__ void wave_sync() {
@@ -50,22 +66,27 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Twiddles of the lane-dependent phases are requested before the transpose that precedes them, so that their LDS
+// latency overlaps it (these two routines serve the latency-bound kernels; the throughput kernel has its own schedule).
 __device__ __forceinline__ void wave_fwd(c64 (&v)[8], int lane, c64 *scratch, const PhaseAConsts &twu, const TwLds &twl) {
+    TwPre<4> twb, twc;
+    tw_preload(twb, twl, TWS_FB);
     fwd_phaseA(v, twu);
 #pragma unroll
     for (int r = 0; r < 8; r++) scratch[swz(fwd_xA(lane, r))] = v[r];
     wave_sync();
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xB(lane, r))];
+    tw_preload(twc, twl, TWS_FC);
     wave_sync();
-    fwd_phaseB(v, twl);
+    fwd_phaseB(v, TwView<4, TWS_FB>{twb});
 #pragma unroll
     for (int r = 0; r < 8; r++) scratch[swz(fwd_xB(lane, r))] = v[r];
     wave_sync();
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xC(lane, r))];
     wave_sync();
-    fwd_phaseC(v, twl);
+    fwd_phaseC(v, TwView<4, TWS_FC>{twc});
 }
 
 // element index inside one half (fixed y3) of the 1024-entry inverse working array
@@ -74,6 +95,10 @@ __device__ __forceinline__ int inv_elem(int y) { return ((y >> 4) << 3) | (y & 7
 template <bool BOUNDED>
 __device__ __forceinline__ void wave_inv(int32_t (&out)[16], c64 (&v)[16], int lane, c64 *scratch,
                                          const PhaseAConsts &twu, const TwLds &twl) {
+    TwPre<7> pb;   // levels 4..6
+    TwPre<8> pc;   // levels 7..9
+    TwPre<8> pf;   // last merge
+    tw_preload(pb, twl, TWS_IB);
     inv_phaseA(v, twu);
     c64 w[16];
     // layout A (regs y3y2y1y0) -> layout B (regs y6y5y4,y3), one half (y3) at a time through the 8 KB scratch
@@ -84,9 +109,10 @@ __device__ __forceinline__ void wave_inv(int32_t (&out)[16], c64 (&v)[16], int l
         wave_sync();
 #pragma unroll
         for (int q = 0; q < 8; q++) w[(q << 1) | h] = scratch[swz(inv_elem(inv_yB(lane, (q << 1) | h)))];
+        if (h == 1) tw_preload(pc, twl, TWS_IC);
         wave_sync();
     }
-    inv_phaseB(w, twl);
+    inv_phaseB(w, TwView<7, TWS_IB>{pb});
     // layout B -> layout C (regs y9y8y7,y3)
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -95,10 +121,11 @@ __device__ __forceinline__ void wave_inv(int32_t (&out)[16], c64 (&v)[16], int l
         wave_sync();
 #pragma unroll
         for (int q = 0; q < 8; q++) v[(q << 1) | h] = scratch[swz(inv_elem(inv_yC(lane, (q << 1) | h)))];
+        if (h == 1) tw_preload(pf, twl, TWS_FIN);
         wave_sync();
     }
-    inv_phaseC(v, twl);
-    inv_final<BOUNDED>(out, v, twl);
+    inv_phaseC(v, TwView<8, TWS_IC>{pc});
+    inv_final<BOUNDED>(out, v, TwView<8, TWS_FIN>{pf});
 }
 
 // spectrum held as (lane, r) <-> physical slot x = r<<6|lane  ->  inverse-transform input registers, via scratch
@@ -450,6 +477,141 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
         }
 #pragma unroll
         for (int q = 0; q < 32; q++) io[q * 64 + lane] = acc[q * 64 + lane];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// blind rotation, latency shape: ONE WORKGROUP (6 waves) per ciphertext, for batches that cannot fill the chip.
+// Per CMux: wave w transforms decomposition row w (column c = w/3, digit p = w%3) and multiplies it with key row w;
+// the six products P_w are summed in row order by the two waves that then run the two inverse transforms -
+// ((((P_0 + P_1) + P_2) + P_3) + P_4) + P_5 with P_w rounded on its own is exactly what the reference's
+// clear-then-AddMul loop computes (tgsw-fft-operations.cpp:108-114), so results stay bit-identical.
+// Critical path per CMux: one forward + one inverse transform instead of six + two.
+// LDS: twiddle image | accumulator 8 KB | per wave: A (scratch, then product column 0) 8 KB, B (product column 1) 8 KB
+//      | the 630 rotation amounts (computed once, so that no global load sits on the per-iteration critical path)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kCoopWaves = 6;
+constexpr int kCoopLds = kTwLaneEntries * (int) sizeof(c64) + 2 * kN * 4 + kCoopWaves * 2 * kNh * (int) sizeof(c64) + 640 * 4;
+
+template <int MODE>
+__global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
+    load_tw_to_lds(tw_lds, A.tw);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int32_t *acc = reinterpret_cast<int32_t *>(lds_raw + kTwLaneEntries * sizeof(c64));
+    c64 *bufs = reinterpret_cast<c64 *>(lds_raw + kTwLaneEntries * sizeof(c64) + 2 * kN * 4);
+    c64 *mineA = bufs + (size_t) wave * 2 * kNh, *mineB = mineA + kNh;
+    const long long g = blockIdx.x;  // host launches exactly B workgroups
+    const PhaseAConsts twu = A.ka;
+    const TwLds twl{tw_lds + lane};
+    const int c = wave >= kL ? 1 : 0, p = wave - c * kL;
+
+    const int32_t *ga = nullptr, *gb = nullptr;
+    int32_t sa = A.sa, sb = A.sb, cst = A.cst;
+    const int32_t *gbara = nullptr;
+    if (MODE == MODE_GATE) {
+        ga = A.a + g * kCt;
+        gb = A.b ? A.b + g * kCt : nullptr;
+        if (A.jobs) {
+            const BrJob *j = A.jobs + g;
+            const int ia = __builtin_amdgcn_readfirstlane(j->ia), ib = __builtin_amdgcn_readfirstlane(j->ib);
+            sa = __builtin_amdgcn_readfirstlane(j->sa);
+            sb = __builtin_amdgcn_readfirstlane(j->sb);
+            cst = __builtin_amdgcn_readfirstlane(j->cst);
+            ga = A.a + (long long) ia * kCt;
+            gb = ib >= 0 ? A.a + (long long) ib * kCt : nullptr;
+        }
+    } else {
+        gbara = A.bara + g * kLwe;
+    }
+    auto comb = [&](int i) -> int32_t {
+        uint32_t t = (uint32_t) sa * (uint32_t) ga[i];
+        if (gb) t += (uint32_t) sb * (uint32_t) gb[i];
+        return (int32_t) t;
+    };
+    int32_t *bara_lds = reinterpret_cast<int32_t *>(bufs + (size_t) kCoopWaves * 2 * kNh);
+    for (int i = threadIdx.x; i < kLwe; i += 64 * kCoopWaves)
+        bara_lds[i] = MODE == MODE_GATE ? modswitch_2N(comb(i)) : (gbara[i] & (2 * kN - 1));
+    if (MODE == MODE_GATE) {
+        const int barb = modswitch_2N((int32_t) ((uint32_t) comb(kLwe) + (uint32_t) cst));
+        for (int j = threadIdx.x; j < kN; j += 64 * kCoopWaves) {
+            acc[j] = 0;
+            acc[kN + j] = ((j + barb) & kN) ? (int32_t) (0u - (uint32_t) A.mu) : A.mu;
+        }
+    } else {
+        int32_t *io = A.acc_io + g * 2 * kN;
+        for (int j = threadIdx.x; j < 2 * kN; j += 64 * kCoopWaves) acc[j] = io[j];
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int i = 0; i < kLwe; i++) {
+        const int bara = __builtin_amdgcn_readfirstlane(bara_lds[i]);
+        if (bara == 0) continue;  // workgroup-uniform
+        const c64 *row = A.bk + ((size_t) i * kKpl + wave) * 2 * kNh + lane;
+        c64 kb[2][8];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) kb[c2][r] = row[c2 * kNh + r * 64];
+        c64 v[8];
+        const int32_t *accc = acc + c * kN;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int j = (br3(r) << 6) | lane;
+            v[r] = {(double) decomp_digit(decomp_prepare(rot_minus_one(accc, bara, j)), p),
+                    (double) decomp_digit(decomp_prepare(rot_minus_one(accc, bara, j + kNh)), p)};
+        }
+        wave_fwd(v, lane, mineA, twu, twl);
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 8; r++) {  // P_w = v * key row w (LagrangeHalfCPolynomialAddMul on a cleared accumulator)
+            const double ac0 = v[r].re * kb[0][r].re, bd0 = v[r].im * kb[0][r].im, ad0 = v[r].re * kb[0][r].im,
+                         bc0 = v[r].im * kb[0][r].re;
+            mineA[r * 64 + lane] = {ac0 - bd0, ad0 + bc0};
+            const double ac1 = v[r].re * kb[1][r].re, bd1 = v[r].im * kb[1][r].im, ad1 = v[r].re * kb[1][r].im,
+                         bc1 = v[r].im * kb[1][r].re;
+            mineB[r * 64 + lane] = {ac1 - bd1, ad1 + bc1};
+        }
+        __syncthreads();  // all six products in LDS; every wave is done reading the accumulator
+        if (wave < 2) {   // wave 0: column 0, wave 1: column 1
+            c64 sum[8];
+            const c64 *src = bufs + (size_t) wave * kNh + lane;
+#pragma unroll
+            for (int r = 0; r < 8; r++) sum[r] = src[r * 64];
+#pragma unroll
+            for (int w = 1; w < kCoopWaves; w++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const c64 t = src[(size_t) w * 2 * kNh + r * 64];
+                    sum[r].re += t.re;
+                    sum[r].im += t.im;
+                }
+            wave_sync();
+            c64 x[16];
+            int32_t res[16];
+            c64 *scratch = wave == 0 ? mineA : mineB;  // own product buffer: only this wave read it
+            spectrum_to_inv_input(x, sum, lane, scratch);
+            wave_inv<true>(res, x, lane, scratch, twu, twl);
+            int32_t *dst = acc + wave * kN;
+#pragma unroll
+            for (int rho = 0; rho < 16; rho++) {
+                const int y = inv_yC(lane, rho);
+                dst[y] = (int32_t) ((uint32_t) dst[y] + (uint32_t) res[rho]);
+            }
+        }
+        __syncthreads();  // accumulator updated
+    }
+
+    if (MODE == MODE_GATE) {
+        int32_t *o = A.out + g * kExt;
+        for (int j = threadIdx.x; j < kN; j += 64 * kCoopWaves) o[j] = j == 0 ? acc[0] : (int32_t) (0u - (uint32_t) acc[kN - j]);
+        if (threadIdx.x == 0) o[kN] = acc[kN];
+    } else {
+        int32_t *io = A.acc_io + g * 2 * kN;
+        for (int j = threadIdx.x; j < 2 * kN; j += 64 * kCoopWaves) io[j] = acc[j];
     }
 }
 
@@ -908,7 +1070,7 @@ struct tfhe_hip_ctx {
     std::vector<uint8_t> h_mark;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // br start/stop, ks start/stop
     bool ev_br = false, ev_ks = false;
-    int br_waves = 0;  // 0 = by batch size; TFHE_HIP_BR_WAVES=1|4|8 forces a shape
+    int br_waves = 0;  // 0 = by batch size; TFHE_HIP_BR_WAVES=1|4|8 forces a shape, 6 the one-workgroup-per-ciphertext kernel
 };
 
 namespace {
@@ -951,7 +1113,16 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
     // waves per workgroup: 8 (two per SIMD) is the throughput shape.  Batches that cannot fill the chip that way run
     // with fewer waves per CU, which finish sooner (measured per wave: 8 per CU 16.4 ms, 4 per CU 10.5 ms, alone 8.8 ms)
     int waves = c->br_waves;
-    if (waves == 0) waves = A.B <= 256 ? 1 : A.B <= 1024 ? 4 : 8;
+    if (waves == 0) waves = A.B <= 256 ? (MODE == MODE_EXTMUL ? 1 : kCoopWaves) : A.B <= 1024 ? 4 : 8;
+    if (waves == kCoopWaves && MODE != MODE_EXTMUL) {  // one workgroup per ciphertext (latency shape)
+        HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate_coop<MODE == MODE_EXTMUL ? MODE_RAW : MODE>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kCoopLds));
+        hipLaunchKernelGGL((k_blind_rotate_coop<MODE == MODE_EXTMUL ? MODE_RAW : MODE>), dim3((unsigned) A.B),
+                           dim3(64 * kCoopWaves), kCoopLds, c->stream, A);
+        HIPCHK(hipGetLastError());
+        return TFHE_HIP_OK;
+    }
+    if (waves == kCoopWaves) waves = 1;
     const size_t lds = kTwLaneEntries * sizeof(c64) + (size_t) waves * kBrLdsPerWave;
     const unsigned grid = (unsigned) ((A.B + waves - 1) / waves);
     auto go = [&](auto kernel) -> int {
@@ -1048,7 +1219,7 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     c->device = device;
     c->ka = make_phaseA_consts([&](int i) { return tw[i]; });
     const char *w = getenv("TFHE_HIP_BR_WAVES");
-    if (w && (atoi(w) == 8 || atoi(w) == 4 || atoi(w) == 1)) c->br_waves = atoi(w);
+    if (w && (atoi(w) == 8 || atoi(w) == 4 || atoi(w) == 1 || atoi(w) == kCoopWaves)) c->br_waves = atoi(w);
     const char *km = getenv("TFHE_HIP_KS_MFMA");
     if (km) c->ks_mfma = atoi(km) != 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
