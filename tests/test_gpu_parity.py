@@ -172,3 +172,24 @@ def test_full_size_batch_16384_and_mux(engine, client, keys, oracle, okeys):
     mux = engine.gate_batch(Gate.MUX, ca[:m], cb[:m], cc)
     dec, _ = client.decrypt(keys, mux)
     assert np.array_equal(dec, np.where(a[:m] == 1, b[:m], c[:m]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["1", "4", "6", "8"])
+def test_every_launch_shape_gives_the_reference_ciphertexts(shape, keys, monkeypatch):
+    """the blind rotation picks waves-per-workgroup by batch size (6 = one workgroup per ciphertext); every shape,
+    forced here through TFHE_HIP_BR_WAVES, must reproduce the reference's outputs of tests/golden/gates.npz"""
+    import os
+    from tfhe_amd import Engine, Gate
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gates.npz"))
+    monkeypatch.setenv("TFHE_HIP_BR_WAVES", shape)
+    eng = Engine(0)
+    try:
+        eng.load_keys_coef(keys.bk_coef, keys.ks)
+        for gate in (Gate.NAND, Gate.XOR, Gate.ANDYN):
+            out = eng.gate_batch(gate, g["ca"][:4], g["cb"][:4])
+            assert np.array_equal(out, g["out"][int(gate), :4]), (shape, gate)
+        out = eng.gate_batch(Gate.MUX, g["ca"], g["cb"], g["cc"])
+        assert np.array_equal(out, g["out"][int(Gate.MUX)]), shape
+    finally:
+        eng.close()

@@ -489,9 +489,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
 // Critical path per CMux: one forward + one inverse transform instead of six + two.
 // LDS: twiddle image | accumulator 8 KB | per wave: A (scratch, then product column 0) 8 KB, B (product column 1) 8 KB
 //      | the 630 rotation amounts (computed once, so that no global load sits on the per-iteration critical path)
+//      | prepared differences 8 KB (see prepare_diff)
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kCoopWaves = 6;
-constexpr int kCoopLds = kTwLaneEntries * (int) sizeof(c64) + 2 * kN * 4 + kCoopWaves * 2 * kNh * (int) sizeof(c64) + 640 * 4;
+constexpr int kCoopLds = kTwLaneEntries * (int) sizeof(c64) + 2 * kN * 4 + kCoopWaves * 2 * kNh * (int) sizeof(c64) + 640 * 4 +
+                         2 * kN * 4;
 
 template <int MODE>
 __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A) {
@@ -532,6 +534,7 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
         return (int32_t) t;
     };
     int32_t *bara_lds = reinterpret_cast<int32_t *>(bufs + (size_t) kCoopWaves * 2 * kNh);
+    uint32_t *diff = reinterpret_cast<uint32_t *>(bara_lds + 640);  // [2][N]: decomp_prepare((X^a - 1) * ACC), next a
     for (int i = threadIdx.x; i < kLwe; i += 64 * kCoopWaves)
         bara_lds[i] = MODE == MODE_GATE ? modswitch_2N(comb(i)) : (gbara[i] & (2 * kN - 1));
     if (MODE == MODE_GATE) {
@@ -546,10 +549,37 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
     }
     __syncthreads();
 
+    // first iteration that is not skipped (bara = 0 is skipped: lwe-bootstrapping-functions-fft.cpp:154)
+    auto next_active = [&](int i) {
+        while (i < kLwe && __builtin_amdgcn_readfirstlane(bara_lds[i]) == 0) i++;
+        return i;
+    };
+    // Waves 0 and 1 own accumulator column `wave`: they keep it in registers (layout inv_yC), mirror it in LDS, and
+    // after each update prepare the rotated difference (X^a - 1) * ACC for the NEXT active iteration, offset added
+    // and digit sign bits flipped, so that the six forward waves only read, extract their digit and convert.
+    int32_t own[16];
+    auto prepare_diff = [&](int a) {
+        const int32_t *col = acc + wave * kN;
+        uint32_t *d = diff + wave * kN;
+#pragma unroll
+        for (int rho = 0; rho < 16; rho++) {
+            const int y = inv_yC(lane, rho);
+            const int sft = (y - a) & (2 * kN - 1);
+            const uint32_t vv = (uint32_t) col[sft & (kN - 1)];
+            const uint32_t rot = (sft & kN) ? (0u - vv) : vv;   // torusPolynomialMulByXaiMinusOne, :106-124
+            d[y] = decomp_prepare((int32_t) (rot - (uint32_t) own[rho]));
+        }
+    };
+    int i = next_active(0);
+    if (wave < 2) {
+#pragma unroll
+        for (int rho = 0; rho < 16; rho++) own[rho] = acc[wave * kN + inv_yC(lane, rho)];
+        if (i < kLwe) prepare_diff(__builtin_amdgcn_readfirstlane(bara_lds[i]));
+    }
+    __syncthreads();
+
 #pragma unroll 1
-    for (int i = 0; i < kLwe; i++) {
-        const int bara = __builtin_amdgcn_readfirstlane(bara_lds[i]);
-        if (bara == 0) continue;  // workgroup-uniform
+    while (i < kLwe) {
         const c64 *row = A.bk + ((size_t) i * kKpl + wave) * 2 * kNh + lane;
         c64 kb[2][8];
 #pragma unroll
@@ -557,13 +587,10 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
 #pragma unroll
             for (int r = 0; r < 8; r++) kb[c2][r] = row[c2 * kNh + r * 64];
         c64 v[8];
-        const int32_t *accc = acc + c * kN;
+        const uint32_t *dcol = diff + c * kN + lane;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int j = (br3(r) << 6) | lane;
-            v[r] = {(double) decomp_digit(decomp_prepare(rot_minus_one(accc, bara, j)), p),
-                    (double) decomp_digit(decomp_prepare(rot_minus_one(accc, bara, j + kNh)), p)};
-        }
+        for (int r = 0; r < 8; r++)
+            v[r] = {(double) decomp_digit(dcol[br3(r) << 6], p), (double) decomp_digit(dcol[(br3(r) << 6) + kNh], p)};
         wave_fwd(v, lane, mineA, twu, twl);
         wave_sync();
 #pragma unroll
@@ -575,7 +602,8 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
                          bc1 = v[r].im * kb[1][r].re;
             mineB[r * 64 + lane] = {ac1 - bd1, ad1 + bc1};
         }
-        __syncthreads();  // all six products in LDS; every wave is done reading the accumulator
+        const int inext = next_active(i + 1);
+        __syncthreads();  // all six products in LDS; every wave is done reading the differences
         if (wave < 2) {   // wave 0: column 0, wave 1: column 1
             c64 sum[8];
             const c64 *src = bufs + (size_t) wave * kNh + lane;
@@ -597,12 +625,15 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
             wave_inv<true>(res, x, lane, scratch, twu, twl);
             int32_t *dst = acc + wave * kN;
 #pragma unroll
-            for (int rho = 0; rho < 16; rho++) {
-                const int y = inv_yC(lane, rho);
-                dst[y] = (int32_t) ((uint32_t) dst[y] + (uint32_t) res[rho]);
+            for (int rho = 0; rho < 16; rho++) {  // tLweAddTo (tlwe-functions.cpp:149)
+                own[rho] = (int32_t) ((uint32_t) own[rho] + (uint32_t) res[rho]);
+                dst[inv_yC(lane, rho)] = own[rho];
             }
+            wave_sync();
+            if (inext < kLwe) prepare_diff(__builtin_amdgcn_readfirstlane(bara_lds[inext]));
         }
-        __syncthreads();  // accumulator updated
+        i = inext;
+        __syncthreads();  // accumulator and next differences in place
     }
 
     if (MODE == MODE_GATE) {
