@@ -554,28 +554,28 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
         while (i < kLwe && __builtin_amdgcn_readfirstlane(bara_lds[i]) == 0) i++;
         return i;
     };
-    // Waves 0 and 1 own accumulator column `wave`: they keep it in registers (layout inv_yC), mirror it in LDS, and
-    // after each update prepare the rotated difference (X^a - 1) * ACC for the NEXT active iteration, offset added
-    // and digit sign bits flipped, so that the six forward waves only read, extract their digit and convert.
-    int32_t own[16];
+    // all threads: diff = decomp_prepare((X^a - 1) * ACC) for the coming iteration (torusPolynomialMulByXaiMinusOne,
+    // toruspolynomial-functions.cpp:106-124), so that the forward waves only read, extract their digit and convert
     auto prepare_diff = [&](int a) {
-        const int32_t *col = acc + wave * kN;
-        uint32_t *d = diff + wave * kN;
-#pragma unroll
-        for (int rho = 0; rho < 16; rho++) {
-            const int y = inv_yC(lane, rho);
-            const int sft = (y - a) & (2 * kN - 1);
-            const uint32_t vv = (uint32_t) col[sft & (kN - 1)];
-            const uint32_t rot = (sft & kN) ? (0u - vv) : vv;   // torusPolynomialMulByXaiMinusOne, :106-124
-            d[y] = decomp_prepare((int32_t) (rot - (uint32_t) own[rho]));
+        for (int e = threadIdx.x; e < 2 * kN; e += 64 * kCoopWaves) {
+            const int32_t *col = acc + (e & kN);
+            diff[e] = decomp_prepare(rot_minus_one(col, a, e & (kN - 1)));
         }
     };
+    // The summed spectrum of column `col` (512 values, 8 KB) lies, between the sum and the start of the inverse
+    // transform, over that column's accumulator mirror and difference buffer (4 KB each): both are dead in that
+    // window and are rewritten before their next use.
+    auto sum_slot = [&](int col, int idx) -> c64 * {
+        c64 *lo = reinterpret_cast<c64 *>(acc + col * kN), *hi = reinterpret_cast<c64 *>(diff + col * kN);
+        return idx < kNh / 2 ? lo + idx : hi + (idx - kNh / 2);
+    };
     int i = next_active(0);
+    int32_t own[16];  // waves 0 and 1: accumulator column `wave`, layout inv_yC
     if (wave < 2) {
 #pragma unroll
         for (int rho = 0; rho < 16; rho++) own[rho] = acc[wave * kN + inv_yC(lane, rho)];
-        if (i < kLwe) prepare_diff(__builtin_amdgcn_readfirstlane(bara_lds[i]));
     }
+    if (i < kLwe) prepare_diff(__builtin_amdgcn_readfirstlane(bara_lds[i]));
     __syncthreads();
 
 #pragma unroll 1
@@ -604,36 +604,46 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
         }
         const int inext = next_active(i + 1);
         __syncthreads();  // all six products in LDS; every wave is done reading the differences
+        // sum over the rows, in row order, by all threads: element e = (column, physical slot x)
+        for (int e = threadIdx.x; e < 2 * kNh; e += 64 * kCoopWaves) {
+            const int col = e >> 9, x = e & (kNh - 1);
+            const c64 *src = bufs + (size_t) col * kNh + x;
+            c64 t = src[0];
+#pragma unroll
+            for (int w = 1; w < kCoopWaves; w++) {
+                const c64 u = src[(size_t) w * 2 * kNh];
+                t.re += u.re;
+                t.im += u.im;
+            }
+            *sum_slot(col, swz(x)) = t;
+        }
+        __syncthreads();  // summed spectra in place
         if (wave < 2) {   // wave 0: column 0, wave 1: column 1
-            c64 sum[8];
-            const c64 *src = bufs + (size_t) wave * kNh + lane;
-#pragma unroll
-            for (int r = 0; r < 8; r++) sum[r] = src[r * 64];
-#pragma unroll
-            for (int w = 1; w < kCoopWaves; w++)
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const c64 t = src[(size_t) w * 2 * kNh + r * 64];
-                    sum[r].re += t.re;
-                    sum[r].im += t.im;
-                }
-            wave_sync();
             c64 x[16];
             int32_t res[16];
-            c64 *scratch = wave == 0 ? mineA : mineB;  // own product buffer: only this wave read it
-            spectrum_to_inv_input(x, sum, lane, scratch);
-            wave_inv<true>(res, x, lane, scratch, twu, twl);
+#pragma unroll
+            for (int rho = 0; rho < 16; rho++) {  // as spectrum_to_inv_input, reading the summed spectrum
+                const int m = (br4(rho) << 6) | lane;
+                if (br4(rho) < 8) {
+                    x[rho] = *sum_slot(wave, swz(gray(m)));
+                } else {
+                    const c64 t = *sum_slot(wave, swz(gray(1023 - m)));
+                    x[rho] = {t.re, -t.im};
+                }
+            }
+            wave_sync();
+            wave_inv<true>(res, x, lane, wave == 0 ? mineA : mineB, twu, twl);
             int32_t *dst = acc + wave * kN;
 #pragma unroll
             for (int rho = 0; rho < 16; rho++) {  // tLweAddTo (tlwe-functions.cpp:149)
                 own[rho] = (int32_t) ((uint32_t) own[rho] + (uint32_t) res[rho]);
                 dst[inv_yC(lane, rho)] = own[rho];
             }
-            wave_sync();
-            if (inext < kLwe) prepare_diff(__builtin_amdgcn_readfirstlane(bara_lds[inext]));
         }
+        __syncthreads();  // accumulator updated
+        if (inext < kLwe) prepare_diff(__builtin_amdgcn_readfirstlane(bara_lds[inext]));
         i = inext;
-        __syncthreads();  // accumulator and next differences in place
+        __syncthreads();  // next differences in place
     }
 
     if (MODE == MODE_GATE) {
