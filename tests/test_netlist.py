@@ -85,3 +85,35 @@ def test_level_contract_is_enforced(engine):
     with pytest.raises(TfheHipError):   # out of range
         engine.gate_level_dev(d_pool, 4, [[0, 4, 0, 1, -1]])
     engine.dev_free(d_pool)
+
+
+@pytest.mark.gpu
+def test_long_run_of_random_gates(engine, client, keys):
+    """the reference's noise-drift soak test (src/test/test-long-run.cpp:61-183) in batched form: W independent pools
+    of 50 ciphertexts; every step applies one random gate (all 11 bootstrapped kinds incl. MUX, plus NOT) per pool to
+    random rows of that pool, all W gates of a step as one level.  Every ciphertext must decrypt to the plaintext
+    simulation throughout, and the outputs of bootstrapped gates must stay within 1/16 of +-1/8 (:179-183)."""
+    from tfhe_amd.truth import TRUTH
+    W, R, steps = 32, 50, 120
+    rng = np.random.default_rng(2024)
+    plain = rng.integers(0, 2, (W, R)).astype(np.uint8)
+    pool = client.encrypt(keys, plain.reshape(-1), seed=99)
+    d_pool = engine.dev_alloc(pool.nbytes)
+    engine.to_dev(d_pool, pool)
+    fresh = np.zeros((W, R), bool)                       # rows last written by a bootstrapped gate
+    kinds = list(range(0, 11)) + [int(Gate.NOT)]
+    for step in range(steps):
+        level = np.full((W, 5), -1, np.int32)
+        for k in range(W):
+            gate = kinds[rng.integers(0, len(kinds))]
+            o, a, b, c = rng.choice(R, 4, replace=False)  # output row distinct from the inputs, as in the reference
+            level[k] = (gate, k * R + o, k * R + a, k * R + b, k * R + c)
+            plain[k, o] = TRUTH[gate](plain[k, a:a + 1], plain[k, b:b + 1], plain[k, c:c + 1])[0]
+            fresh[k, o] = gate <= int(Gate.MUX)
+        engine.gate_level_dev(d_pool, W * R, level)
+        if step % 40 == 39 or step == steps - 1:
+            bits, phases = client.decrypt(keys, engine.from_dev(d_pool, pool.shape))
+            assert np.array_equal(bits.reshape(W, R), plain), "step %d" % step
+            resid = np.abs(np.abs(phases.astype(np.int64)) - (1 << 29)).reshape(W, R)[fresh]
+            assert resid.max() < (1 << 28), resid.max()
+    engine.dev_free(d_pool)
