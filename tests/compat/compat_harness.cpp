@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <time.h>
 #include "tfhe_hip_compat.h"
 
 static const int n = TFHE_HIP_n, N = TFHE_HIP_N, KPL = TFHE_HIP_KPL, T = TFHE_HIP_KS_T, BASE = TFHE_HIP_KS_BASE;
@@ -129,6 +130,28 @@ void harness_gate(void *p, int gate, int32_t *out, const int32_t *a, const int32
         out[(size_t) i * (n + 1) + n] = r[i].b;
     }
     free_samples(sc, count); free_samples(sb, count); free_samples(sa, count); free_samples(r, count);
+}
+
+// throughput of the struct-level path alone: `count` NAND gates on LweSample arrays that already exist (what an
+// application written against libtfhe holds); returns milliseconds per call
+double harness_time_nand(void *p, const int32_t *a, const int32_t *b, int32_t *out, int count, int reps) {
+    Holder *h = (Holder *) p;
+    LweSample *r = new_samples(count, n), *sa = new_samples(count, n), *sb = new_samples(count, n);
+    for (int i = 0; i < count; i++) {
+        memcpy(sa[i].a, a + (size_t) i * (n + 1), 4 * n); sa[i].b = a[(size_t) i * (n + 1) + n];
+        memcpy(sb[i].a, b + (size_t) i * (n + 1), 4 * n); sb[i].b = b[(size_t) i * (n + 1) + n];
+    }
+    bootsNAND_batch(r, sa, sb, count, &h->cloud);   // warm-up (key upload on first use)
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int k = 0; k < reps; k++) bootsNAND_batch(r, sa, sb, count, &h->cloud);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int i = 0; i < count; i++) {
+        memcpy(out + (size_t) i * (n + 1), r[i].a, 4 * n);
+        out[(size_t) i * (n + 1) + n] = r[i].b;
+    }
+    free_samples(sb, count); free_samples(sa, count); free_samples(r, count);
+    return ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6) / reps;
 }
 
 // the reference seam: tfhe_blindRotate_FFT(accum, bkFFT, bara, n, bk_params)

@@ -92,3 +92,22 @@ def test_reference_seam_signature(keyset, oracle, okeys):
     want = oracle.blind_rotate(okeys, acc, bara)
     lib.harness_blind_rotate(h, P(acc), P(bara))
     assert np.array_equal(acc, want)
+
+
+@pytest.mark.gpu
+def test_chunked_struct_path_on_a_large_ragged_batch(keyset, client, keys, engine):
+    """tfhe_hip_gate_batch_samples packs LweSample arrays chunk by chunk (4,096) with a helper thread; a batch that
+    spans three chunks with a ragged tail must equal the flat entry point's output row for row"""
+    lib, h = keyset
+    lib.harness_time_nand.restype = ctypes.c_double
+    count = 2 * 4096 + 123
+    rng = np.random.default_rng(77)
+    a, b = rng.integers(0, 2, count).astype(np.uint8), rng.integers(0, 2, count).astype(np.uint8)
+    ca, cb = client.encrypt(keys, a, 41), client.encrypt(keys, b, 42)
+    out = np.zeros((count, PR.n + 1), np.int32)
+    ms = lib.harness_time_nand(h, P(ca), P(cb), P(out), count, 1)
+    from tfhe_amd import Gate
+    assert np.array_equal(out, engine.gate_batch(Gate.NAND, ca, cb))
+    dec, _ = client.decrypt(keys, out)
+    assert np.array_equal(dec, 1 - (a & b))
+    print("struct-level bootsNAND_batch: %d gates in %.1f ms" % (count, ms))

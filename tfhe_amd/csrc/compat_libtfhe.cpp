@@ -3,7 +3,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "../../include/tfhe_hip_compat.h"
 
@@ -85,22 +87,51 @@ int tfhe_hip_load_cloud_keyset(tfhe_hip_ctx *ctx, const TFheGateBootstrappingClo
     return load_keys(ctx, k->bkFFT, k->ks);
 }
 
+// The pointer-rich LweSample arrays (each sample owns a separately allocated a[630], lwesamples.cpp:5-10) are packed
+// into flat buffers chunk by chunk; a helper thread scatters the results of chunk k-1 and packs chunk k+1 while the GPU
+// works on chunk k, so that the packing (165 MB of small copies per 16,384 NAND gates) hides behind the kernels.
 int tfhe_hip_gate_batch_samples(tfhe_hip_ctx *ctx, int gate, LweSample *result, const LweSample *a,
                                 const LweSample *b, const LweSample *c, int32_t count) {
     if (!ctx || count < 0 || (count > 0 && !result)) return TFHE_HIP_ERR_ARG;
     if (count == 0) return TFHE_HIP_OK;
-    std::vector<int32_t> fa, fb, fc, fo((size_t) count * (kn + 1));
-    if (a) pack(fa, a, count);
-    if (b) pack(fb, b, count);
-    if (c) pack(fc, c, count);
-    int rc = tfhe_hip_gate_batch(ctx, gate, fo.data(), a ? fa.data() : nullptr, b ? fb.data() : nullptr,
-                                 c ? fc.data() : nullptr, count);
-    if (rc != 0) return rc;
-    for (int32_t i = 0; i < count; i++) {
-        std::memcpy(result[i].a, fo.data() + (size_t) i * (kn + 1), sizeof(int32_t) * kn);
-        result[i].b = fo[(size_t) i * (kn + 1) + kn];
-        result[i].current_variance = 0.;   // bookkeeping only in the reference (SURVEY 8(a) note 2)
+    constexpr int32_t kChunk = 4096;  // two full rounds of the blind-rotation kernel on one GPU
+    struct Chunk {
+        std::vector<int32_t> fa, fb, fc, fo;
+        int32_t off = 0, n = 0;
+    } ch[2];
+    auto pack_chunk = [&](Chunk &k, int32_t off) {
+        k.off = off;
+        k.n = std::min(kChunk, count - off);
+        if (a) pack(k.fa, a + off, k.n);
+        if (b) pack(k.fb, b + off, k.n);
+        if (c) pack(k.fc, c + off, k.n);
+        k.fo.resize((size_t) k.n * (kn + 1));
+    };
+    auto scatter_chunk = [&](const Chunk &k) {
+        for (int32_t i = 0; i < k.n; i++) {
+            LweSample &r = result[k.off + i];
+            std::memcpy(r.a, k.fo.data() + (size_t) i * (kn + 1), sizeof(int32_t) * kn);
+            r.b = k.fo[(size_t) i * (kn + 1) + kn];
+            r.current_variance = 0.;   // bookkeeping only in the reference (SURVEY 8(a) note 2)
+        }
+    };
+    const int32_t nchunks = (count + kChunk - 1) / kChunk;
+    pack_chunk(ch[0], 0);
+    int rc = TFHE_HIP_OK;
+    for (int32_t k = 0; k < nchunks && rc == TFHE_HIP_OK; k++) {
+        Chunk &cur = ch[k & 1], &other = ch[(k + 1) & 1];
+        std::thread helper;
+        if (nchunks > 1)
+            helper = std::thread([&, k] {
+                if (k > 0) scatter_chunk(other);                       // results of chunk k-1
+                if (k + 1 < nchunks) pack_chunk(other, (k + 1) * kChunk);
+            });
+        rc = tfhe_hip_gate_batch(ctx, gate, cur.fo.data(), a ? cur.fa.data() : nullptr, b ? cur.fb.data() : nullptr,
+                                 c ? cur.fc.data() : nullptr, cur.n);
+        if (helper.joinable()) helper.join();
     }
+    if (rc != TFHE_HIP_OK) return rc;
+    scatter_chunk(ch[(nchunks - 1) & 1]);
     return TFHE_HIP_OK;
 }
 
