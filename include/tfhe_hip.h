@@ -89,7 +89,8 @@ int tfhe_hip_get_bkfft(tfhe_hip_ctx *ctx, double *bkfft_out);
 
 /* ---- batched gates, host buffers in and out (PCIe inclusive) --------------------------------------------------
  * out[count][n+1]; a,b,c[count][n+1]; b/c may be NULL where the gate does not read them.
- * Semantics per element = bootsNAND/.../bootsMUX of boot-gates.cpp. */
+ * Semantics per element = bootsNAND/.../bootsMUX of boot-gates.cpp.  Batches above 4,096 gates run in chunks with the
+ * copies of the neighbouring chunks overlapped on a second stream (tfhe_hip_last_kernel_ms then reports the last chunk). */
 int tfhe_hip_gate_batch(tfhe_hip_ctx *ctx, int gate, int32_t *out, const int32_t *a, const int32_t *b,
                         const int32_t *c, int64_t count);
 /* tfhe_bootstrap_FFT (with_ks != 0, out[count][n+1]; lwe-bootstrapping-functions-fft.cpp:266) or

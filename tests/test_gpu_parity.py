@@ -167,7 +167,7 @@ def test_full_size_batch_16384_and_mux(engine, client, keys, oracle, okeys):
     # batch size do not matter): re-running a slice reproduces the same ciphertexts bit for bit
     again = engine.gate_batch(Gate.NAND, ca[5000:5100], cb[5000:5100])
     assert np.array_equal(again, got[5000:5100])
-    m = 4096
+    m = 4096 + 37   # host-buffer calls above 4,096 gates are pipelined in chunks: a ragged second chunk, three operands
     cc = client.encrypt(keys, c[:m], 303)
     mux = engine.gate_batch(Gate.MUX, ca[:m], cb[:m], cc)
     dec, _ = client.decrypt(keys, mux)

@@ -1128,6 +1128,8 @@ struct DevBuf {
 struct tfhe_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;      // host<->device copies of chunked host-buffer calls
+    std::vector<hipEvent_t> chunk_ev;       // per chunk: inputs landed, kernels done
     c64 *tw = nullptr;
     PhaseAConsts ka{};
     c64 *bk = nullptr;       // [n][6][2][512] physical order
@@ -1295,6 +1297,7 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     const char *km = getenv("TFHE_HIP_KS_MFMA");
     if (km) c->ks_mfma = atoi(km) != 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     std::vector<c64> image(kTwLaneEntries);
     build_lane_twiddles(image.data(), [&](int i) { return tw[i]; });
     if (e == hipSuccess) e = hipMalloc((void **) &c->tw, kTwLaneEntries * sizeof(c64));
@@ -1320,6 +1323,8 @@ void tfhe_hip_destroy(tfhe_hip_ctx *c) {
     if (c->kl) (void) hipFree(c->kl);
     for (int i = 0; i < 4; i++)
         if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
+    for (hipEvent_t ev : c->chunk_ev) (void) hipEventDestroy(ev);
+    if (c->copy_stream) (void) hipStreamDestroy(c->copy_stream);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1497,21 +1502,76 @@ static int d2h(tfhe_hip_ctx *c, void *dst, const void *src, size_t bytes) {
     return TFHE_HIP_OK;
 }
 
+// Host buffers.  Batches above one chunk are pipelined: the copies of chunk k+1 (in) and chunk k-1 (out) run on a
+// second stream while the kernels of chunk k run, so that PCIe time hides behind the blind rotation.
 int tfhe_hip_gate_batch(tfhe_hip_ctx *c, int gate, int32_t *out, const int32_t *a, const int32_t *b, const int32_t *cc,
                         int64_t count) {
     if (int r = check_ctx(c, false)) return r;
     if (count < 0 || (count > 0 && !out)) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
     if (count == 0) return TFHE_HIP_OK;
     const size_t bytes = (size_t) count * kCt * sizeof(int32_t);
-    if (a) if (int r = h2d(c, c->in_a, a, bytes)) return r;
-    if (b) if (int r = h2d(c, c->in_b, b, bytes)) return r;
-    if (cc) if (int r = h2d(c, c->in_c, cc, bytes)) return r;
+    constexpr int64_t kChunk = 4096;  // two full rounds of the blind-rotation kernel
+    if (count <= kChunk) {
+        if (a) if (int r = h2d(c, c->in_a, a, bytes)) return r;
+        if (b) if (int r = h2d(c, c->in_b, b, bytes)) return r;
+        if (cc) if (int r = h2d(c, c->in_c, cc, bytes)) return r;
+        HIPCHK(c->outb.reserve(bytes));
+        if (int r = tfhe_hip_gate_batch_dev(c, gate, (int32_t *) c->outb.p, a ? (const int32_t *) c->in_a.p : nullptr,
+                                            b ? (const int32_t *) c->in_b.p : nullptr,
+                                            cc ? (const int32_t *) c->in_c.p : nullptr, count))
+            return r;
+        return d2h(c, out, c->outb.p, bytes);
+    }
+    if (a) HIPCHK(c->in_a.reserve(bytes));
+    if (b) HIPCHK(c->in_b.reserve(bytes));
+    if (cc) HIPCHK(c->in_c.reserve(bytes));
     HIPCHK(c->outb.reserve(bytes));
-    if (int r = tfhe_hip_gate_batch_dev(c, gate, (int32_t *) c->outb.p, a ? (const int32_t *) c->in_a.p : nullptr,
-                                        b ? (const int32_t *) c->in_b.p : nullptr,
-                                        cc ? (const int32_t *) c->in_c.p : nullptr, count))
-        return r;
-    return d2h(c, out, c->outb.p, bytes);
+    const int64_t nchunks = (count + kChunk - 1) / kChunk;
+    while ((int64_t) c->chunk_ev.size() < 2 * nchunks) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c->chunk_ev.push_back(ev);
+    }
+    auto span = [&](int64_t k, int64_t &off, int64_t &n) {
+        off = k * kChunk;
+        n = count - off < kChunk ? count - off : kChunk;
+    };
+    auto copy_in = [&](int64_t k) -> int {
+        int64_t off, n;
+        span(k, off, n);
+        const size_t o = (size_t) off * kCt, nb = (size_t) n * kCt * sizeof(int32_t);
+        if (a) HIPCHK(hipMemcpyAsync((int32_t *) c->in_a.p + o, a + o, nb, hipMemcpyHostToDevice, c->copy_stream));
+        if (b) HIPCHK(hipMemcpyAsync((int32_t *) c->in_b.p + o, b + o, nb, hipMemcpyHostToDevice, c->copy_stream));
+        if (cc) HIPCHK(hipMemcpyAsync((int32_t *) c->in_c.p + o, cc + o, nb, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(hipEventRecord(c->chunk_ev[2 * k], c->copy_stream));
+        return TFHE_HIP_OK;
+    };
+    auto copy_out = [&](int64_t k) -> int {
+        int64_t off, n;
+        span(k, off, n);
+        const size_t o = (size_t) off * kCt, nb = (size_t) n * kCt * sizeof(int32_t);
+        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->chunk_ev[2 * k + 1], 0));
+        HIPCHK(hipMemcpyAsync(out + o, (int32_t *) c->outb.p + o, nb, hipMemcpyDeviceToHost, c->copy_stream));
+        return TFHE_HIP_OK;
+    };
+    int rc = copy_in(0);
+    for (int64_t k = 0; k < nchunks && rc == TFHE_HIP_OK; k++) {
+        int64_t off, n;
+        span(k, off, n);
+        const size_t o = (size_t) off * kCt;
+        HIPCHK(hipStreamWaitEvent(c->stream, c->chunk_ev[2 * k], 0));
+        rc = tfhe_hip_gate_batch_dev(c, gate, (int32_t *) c->outb.p + o, a ? (const int32_t *) c->in_a.p + o : nullptr,
+                                     b ? (const int32_t *) c->in_b.p + o : nullptr,
+                                     cc ? (const int32_t *) c->in_c.p + o : nullptr, n);
+        if (rc != TFHE_HIP_OK) break;
+        HIPCHK(hipEventRecord(c->chunk_ev[2 * k + 1], c->stream));
+        if (k + 1 < nchunks) rc = copy_in(k + 1);
+        if (rc == TFHE_HIP_OK && k > 0) rc = copy_out(k - 1);
+    }
+    if (rc == TFHE_HIP_OK) rc = copy_out(nchunks - 1);
+    (void) hipStreamSynchronize(c->copy_stream);
+    (void) hipStreamSynchronize(c->stream);
+    return rc;
 }
 
 int tfhe_hip_bootstrap_batch(tfhe_hip_ctx *c, int32_t *out, const int32_t *in, int32_t mu, int64_t count, int with_ks) {
