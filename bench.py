@@ -70,7 +70,8 @@ def cpu_baseline(keys, ca, cb, expect_bits, client):
 def side_bench(args, torch, dev, rank, world):
     """BASELINE configs[4]: bootsMUX batch (two bootstraps + one keyswitch per gate) and the batched negacyclic
     IntPolynomial x TorusPolynomial FFT product at N = 1024 (torusPolynomialMultFFT, reference polynomials.cpp:241).
-    N = 2048 is not offered: the reference's transform is compiled for N = 1024 only (tfhe_core.h:14)."""
+    N = 2048 (--workload fft2048) is composed of four N = 1024 products: the reference's transform is compiled for
+    N = 1024 only (tfhe_core.h:14), its naive product is the oracle there."""
     from tfhe_amd import Client, Engine, Gate, PARAMS as PR
     assert world == 1, "side benches are single-GPU"
     eng = Engine(0)
@@ -89,12 +90,16 @@ def side_bench(args, torch, dev, rank, world):
         unit, per_step, name = "gates/s", B, "bootsMUX gates/sec (2 bootstraps + 1 keyswitch each)"
     else:
         B = 1 << 16
+        n = PR.N if args.workload == "fft" else 2 * PR.N
         rng = np.random.default_rng(6)
-        a = torch.from_numpy(rng.integers(-2 * PR.N, 2 * PR.N, (B, PR.N)).astype(np.int32)).to(dev)
-        b = torch.from_numpy(rng.integers(-2**31, 2**31, (B, PR.N)).astype(np.int32)).to(dev)
-        d_out = torch.empty((B, PR.N), dtype=torch.int32, device=dev)
-        run = lambda: eng.negacyclic_mul_dev(d_out, a, b, B)  # noqa: E731
-        unit, per_step, name = "products/s", B, "negacyclic IntPolynomial x TorusPolynomial FFT products/sec, N=1024"
+        a = torch.from_numpy(rng.integers(-2 * n, 2 * n, (B, n)).astype(np.int32)).to(dev)
+        b = torch.from_numpy(rng.integers(-2**31, 2**31, (B, n)).astype(np.int32)).to(dev)
+        d_out = torch.empty((B, n), dtype=torch.int32, device=dev)
+        if args.workload == "fft":
+            run = lambda: eng.negacyclic_mul_dev(d_out, a, b, B)  # noqa: E731
+        else:   # N = 2048: four N = 1024 products per product (even/odd split), no reference transform exists
+            run = lambda: eng.negacyclic_mul2048_dev(d_out, a, b, B)  # noqa: E731
+        unit, per_step, name = "products/s", B, "negacyclic IntPolynomial x TorusPolynomial FFT products/sec, N=%d" % n
     for _ in range(args.warmup):
         run()
     eng.sync()
@@ -176,7 +181,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=16384, help="gates per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="nand", choices=["nand", "mux", "fft", "adder"],
+    ap.add_argument("--workload", default="nand", choices=["nand", "mux", "fft", "fft2048", "adder"],
                     help="nand: BASELINE configs[1] (default, the headline); adder: configs[3] levelized 32-bit adders; "
                          "mux / fft: configs[4] side benches")
     ap.add_argument("--instances", type=int, default=4096, help="adder workload: independent adder instances")

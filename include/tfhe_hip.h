@@ -144,6 +144,14 @@ int tfhe_hip_negacyclic_mul_batch(tfhe_hip_ctx *ctx, int32_t *out, const int32_t
 int tfhe_hip_negacyclic_mul_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_ipolys,
                                       const int32_t *d_tpolys, int64_t count);
 
+/* the same product at N = 2048 (BASELINE configs[4]): polys int32[count][2048].  The reference has no transform for
+ * N = 2048 (tfhe_core.h:14); the product is composed of four N = 1024 products (even/odd split) and agrees with the
+ * reference's naive product torusPolynomialMultNaive_aux (multiplication.cpp:31-43) within 2 LSB for |ipoly| < 2N */
+int tfhe_hip_negacyclic_mul2048_batch(tfhe_hip_ctx *ctx, int32_t *out, const int32_t *ipolys, const int32_t *tpolys,
+                                      int64_t count);
+int tfhe_hip_negacyclic_mul2048_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_ipolys,
+                                          const int32_t *d_tpolys, int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,8 +11,16 @@ REF_SO = os.path.join(ROOT, "oracle", "_ref", "libtfhe_ref.so")
 n, N, KPL, T, BASE = 630, 1024, 6, 8, 4
 
 
+class _Ptr(ctypes.c_void_p):
+    """pointer that keeps its array alive (a converted temporary would otherwise be freed before the call)"""
+
+
 def P(a):
-    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+    if a is None:
+        return None
+    p = _Ptr(a.ctypes.data)
+    p._keep = a
+    return p
 
 
 def i32(a):

@@ -59,6 +59,31 @@ def test_negacyclic_mul_bit_exact_and_vs_naive(engine, oracle):
         assert np.abs(d).max() <= 1
 
 
+def test_negacyclic_mul_2048_vs_naive(engine, oracle):
+    """BASELINE configs[4], N = 2048: inputs as src/test/test-multiplication.cpp:41-44 (a in [-2N, 2N), b uniform); the
+    oracle is the reference's naive product (no reference transform exists for N = 2048).  The GPU composes four
+    N = 1024 FFT products, so it must (i) equal the same composition of the oracle's N = 1024 FFT products exactly and
+    (ii) stay within 2 LSB of the exact product"""
+    rng = np.random.default_rng(12)
+    N2, cnt = 2 * P.N, 5
+    a = rng.integers(-2 * N2, 2 * N2, (cnt, N2)).astype(np.int32)
+    b = rng.integers(-2**31, 2**31, (cnt, N2)).astype(np.int32)
+    a[0], b[1] = 0, 0
+    got = engine.negacyclic_mul2048(a, b)
+    for g in range(cnt):
+        ae, ao, be, bo = (np.ascontiguousarray(x) for x in (a[g, 0::2], a[g, 1::2], b[g, 0::2], b[g, 1::2]))
+        p0, p1, p2, p3 = (oracle.mul_fft(x, y).astype(np.int64) for x, y in ((ae, be), (ao, bo), (ae, bo), (ao, be)))
+        want = np.empty(N2, np.int64)
+        want[0::2] = p0 + np.concatenate(([-p1[-1]], p1[:-1]))
+        want[1::2] = p2 + p3
+        want = ((want + 2**31) % 2**32 - 2**31).astype(np.int32)
+        assert np.array_equal(got[g], want), g
+        exact = oracle.mul_naive(a[g], b[g]).astype(np.int64)
+        d = (got[g].astype(np.int64) - exact + 2**31) % 2**32 - 2**31
+        assert np.abs(d).max() <= 2, (g, np.abs(d).max())
+    assert not got[0].any() and not got[1].any()
+
+
 def test_external_product_bit_exact(engine, oracle, okeys):
     rng = np.random.default_rng(13)
     acc = rng.integers(-2**31, 2**31, (8, 2, P.N)).astype(np.int32)

@@ -1051,6 +1051,40 @@ __global__ __launch_bounds__(256) void k_poly_mul(const int32_t *__restrict__ ip
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// N = 2048 negacyclic product (BASELINE configs[4] microbench) from four N = 1024 products.  With Y = X^2,
+// a = a_e(Y) + X a_o(Y) and b alike:  a b = (a_e b_e + Y a_o b_o)(Y) + X (a_e b_o + a_o b_e)(Y)  mod X^2048 + 1, and
+// each of the four is a product mod Y^1024 + 1, i.e. the reference's torusPolynomialMultFFT (polynomials.cpp:241) as
+// k_poly_mul computes it; multiplication by Y is a negacyclic shift, the additions are exact mod 2^32.  The reference
+// itself has no transform for N = 2048 (tfhe_core.h:14 fixes N = 1024); its naive product
+// torusPolynomialMultNaive_aux (multiplication.cpp:31-43) is the oracle, reached within 2 LSB.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_split2048(const int32_t *__restrict__ a, const int32_t *__restrict__ b,
+                                                   int32_t *__restrict__ I, int32_t *__restrict__ T, long long count) {
+    const long long idx = (long long) blockIdx.x * 256 + threadIdx.x;  // one thread per (product, j < 1024)
+    if (idx >= count * kN) return;
+    const long long g = idx >> 10;
+    const int j = (int) (idx & (kN - 1));
+    const int32_t ae = a[g * 2 * kN + 2 * j], ao = a[g * 2 * kN + 2 * j + 1];
+    const int32_t be = b[g * 2 * kN + 2 * j], bo = b[g * 2 * kN + 2 * j + 1];
+    int32_t *Ig = I + g * 4 * kN + j, *Tg = T + g * 4 * kN + j;
+    Ig[0] = ae; Tg[0] = be;                  // P0 = a_e b_e
+    Ig[kN] = ao; Tg[kN] = bo;                // P1 = a_o b_o
+    Ig[2 * kN] = ae; Tg[2 * kN] = bo;        // P2 = a_e b_o
+    Ig[3 * kN] = ao; Tg[3 * kN] = be;        // P3 = a_o b_e
+}
+__global__ __launch_bounds__(256) void k_combine2048(const int32_t *__restrict__ P, int32_t *__restrict__ out,
+                                                     long long count) {
+    const long long idx = (long long) blockIdx.x * 256 + threadIdx.x;
+    if (idx >= count * kN) return;
+    const long long g = idx >> 10;
+    const int j = (int) (idx & (kN - 1));
+    const uint32_t *Pg = reinterpret_cast<const uint32_t *>(P) + g * 4 * kN;
+    const uint32_t shifted = j ? Pg[kN + j - 1] : 0u - Pg[kN + kN - 1];  // (Y * P1)[j]
+    out[g * 2 * kN + 2 * j] = (int32_t) (Pg[j] + shifted);
+    out[g * 2 * kN + 2 * j + 1] = (int32_t) (Pg[2 * kN + j] + Pg[3 * kN + j]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 thread_local std::string g_err;
@@ -1677,6 +1711,41 @@ int tfhe_hip_negacyclic_mul_batch(tfhe_hip_ctx *c, int32_t *out, const int32_t *
     HIPCHK(c->outb.reserve(pb));
     if (int r = tfhe_hip_negacyclic_mul_batch_dev(c, (int32_t *) c->outb.p, (const int32_t *) c->in_a.p,
                                                   (const int32_t *) c->in_b.p, count))
+        return r;
+    return d2h(c, out, c->outb.p, pb);
+}
+
+int tfhe_hip_negacyclic_mul2048_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_i, const int32_t *d_t,
+                                          int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || (count > 0 && (!d_out || !d_i || !d_t))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    constexpr int64_t kChunk = 8192;  // workspace: 3 x 4 x 4 KB per product
+    const int64_t first = count < kChunk ? count : kChunk;
+    if (count > 0) HIPCHK(c->misc.reserve((size_t) first * 12 * kN * sizeof(int32_t)));
+    for (int64_t off = 0; off < count; off += kChunk) {
+        const int64_t n = count - off < kChunk ? count - off : kChunk;
+        int32_t *I = (int32_t *) c->misc.p, *T = I + (size_t) first * 4 * kN, *P = T + (size_t) first * 4 * kN;
+        const unsigned blocks = (unsigned) ((n * kN + 255) / 256);
+        hipLaunchKernelGGL(k_split2048, dim3(blocks), dim3(256), 0, c->stream, d_i + off * 2 * kN, d_t + off * 2 * kN, I, T,
+                           (long long) n);
+        HIPCHK(hipGetLastError());
+        if (int r = tfhe_hip_negacyclic_mul_batch_dev(c, P, I, T, 4 * n)) return r;
+        hipLaunchKernelGGL(k_combine2048, dim3(blocks), dim3(256), 0, c->stream, (const int32_t *) P, d_out + off * 2 * kN,
+                           (long long) n);
+        HIPCHK(hipGetLastError());
+    }
+    return TFHE_HIP_OK;
+}
+int tfhe_hip_negacyclic_mul2048_batch(tfhe_hip_ctx *c, int32_t *out, const int32_t *ip, const int32_t *tp, int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || (count > 0 && (!out || !ip || !tp))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    const size_t pb = (size_t) count * 2 * kN * sizeof(int32_t);
+    if (int r = h2d(c, c->in_a, ip, pb)) return r;
+    if (int r = h2d(c, c->in_b, tp, pb)) return r;
+    HIPCHK(c->outb.reserve(pb));
+    if (int r = tfhe_hip_negacyclic_mul2048_batch_dev(c, (int32_t *) c->outb.p, (const int32_t *) c->in_a.p,
+                                                      (const int32_t *) c->in_b.p, count))
         return r;
     return d2h(c, out, c->outb.p, pb);
 }

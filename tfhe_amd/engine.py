@@ -55,6 +55,7 @@ EXPORTS = [
     "tfhe_hip_int_ifft_batch", "tfhe_hip_torus_ifft_batch", "tfhe_hip_torus_fft_batch",
     "tfhe_hip_negacyclic_mul_batch", "tfhe_hip_negacyclic_mul_batch_dev", "tfhe_hip_gate_level_dev",
     "tfhe_hip_dev_alloc", "tfhe_hip_dev_free", "tfhe_hip_copy_to_dev", "tfhe_hip_copy_from_dev",
+    "tfhe_hip_negacyclic_mul2048_batch", "tfhe_hip_negacyclic_mul2048_batch_dev",
 ]
 
 
@@ -259,6 +260,19 @@ class Engine:
         self._chk(self.lib.tfhe_hip_torus_fft_batch(self.ctx, _p(out), _p(s), ctypes.c_int64(s.shape[0])),
                   "torus_fft_batch")
         return out
+
+    def negacyclic_mul2048(self, ipolys, tpolys):
+        a, b = _i32(ipolys, (2 * PARAMS.N,)), _i32(tpolys, (2 * PARAMS.N,))
+        assert a.shape == b.shape
+        out = np.empty_like(a)
+        self._chk(self.lib.tfhe_hip_negacyclic_mul2048_batch(self.ctx, _p(out), _p(a), _p(b),
+                                                             ctypes.c_int64(a.shape[0])), "negacyclic_mul2048_batch")
+        return out
+
+    def negacyclic_mul2048_dev(self, out, ipolys, tpolys, count):
+        self._chk(self.lib.tfhe_hip_negacyclic_mul2048_batch_dev(self.ctx, self._dptr(out), self._dptr(ipolys),
+                                                                 self._dptr(tpolys), ctypes.c_int64(count)),
+                  "negacyclic_mul2048_batch_dev")
 
     def negacyclic_mul(self, ipolys, tpolys):
         P = PARAMS
