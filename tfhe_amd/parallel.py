@@ -79,3 +79,35 @@ def sharded_gate_batch(gate_fn, gate, a, b=None, c=None, gather=True, device=Non
     sl = slice(lo, hi)
     local = gate_fn(gate, a[sl], None if b is None else b[sl], None if c is None else c[sl])
     return all_gather_rows(local, count, device) if gather else local
+
+
+def run_levels_sharded(level_fn, pool, levels):
+    """Levelized netlist over all ranks (BASELINE configs[3]).  Every rank holds the whole ciphertext pool (`pool`: torch
+    int32 tensor [rows, n+1], on this rank's GPU with the nccl backend, on the CPU with gloo); per level each rank
+    evaluates its contiguous block of the level's gates on its own pool - level_fn(gates int32[k][5]), i.e.
+    Engine.gate_level_dev on the GPU box - and the output rows are all-gathered (one collective per level,
+    2,524 B per gate) so that every pool is complete before the next level.  Returns the number of gates evaluated."""
+    import torch
+    dist = _dist()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    total = 0
+    for lv in levels:
+        lv = np.ascontiguousarray(lv, dtype=np.int32).reshape(-1, 5)
+        count = lv.shape[0]
+        total += count
+        lo, hi = shard_bounds(count, rank, world)
+        if hi > lo:
+            level_fn(lv[lo:hi])
+        if world == 1:
+            continue
+        cap = -(-count // world)
+        buf = torch.zeros((cap, pool.shape[1]), dtype=pool.dtype, device=pool.device)
+        if hi > lo:
+            buf[:hi - lo] = pool[torch.from_numpy(lv[lo:hi, 1].astype(np.int64)).to(pool.device)]
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        for r in range(world):
+            rlo, rhi = shard_bounds(count, r, world)
+            if r != rank and rhi > rlo:
+                pool[torch.from_numpy(lv[rlo:rhi, 1].astype(np.int64)).to(pool.device)] = parts[r][:rhi - rlo]
+    return total
