@@ -105,6 +105,32 @@ def test_blind_rotate_seam_bit_exact(engine, oracle, okeys):
         assert np.array_equal(got[i], oracle.blind_rotate(okeys, acc[i], bara[i])), i
 
 
+def test_blind_rotate_rotates_the_message(engine, keys, oracle):
+    """the algebra the reference's unit test checks with fake samples (src/test/bootstrapping_test_fft.cpp:99-144),
+    here with the real noisy key and no oracle in the loop: blind rotation of the trivial sample (0, msg) by bara must
+    decrypt, under the TLWE key, to X^(sum_i s_i bara_i) * msg up to the bootstrapping-key noise"""
+    rng = np.random.default_rng(21)
+    cnt = 3
+    msg = rng.integers(-2**31, 2**31, (cnt, P.N)).astype(np.int32)
+    acc = np.zeros((cnt, 2, P.N), np.int32)
+    acc[:, 1] = msg
+    bara = rng.integers(0, 2 * P.N, (cnt, P.n)).astype(np.int32)
+    out = engine.blind_rotate_batch(acc, bara)
+    s = keys.tlwe_key.astype(np.int32)
+    for g in range(cnt):
+        a_s = oracle.mul_naive(s, out[g, 0])                      # exact negacyclic product: key (binary) * mask
+        phase = (out[g, 1].astype(np.int64) - a_s.astype(np.int64))
+        shift = int((keys.lwe_key.astype(np.int64) * bara[g]).sum() % (2 * P.N))
+        j = np.arange(P.N)
+        src = (j - shift) % (2 * P.N)
+        want = np.where(src >= P.N, -msg[g, src % P.N].astype(np.int64), msg[g, src % P.N].astype(np.int64))
+        err = (phase - want + 2**31) % 2**32 - 2**31
+        # predicted standard deviation: sqrt(n (k+1) l N (Bg/2)^2) * 2^-25 = 2^-8 of the torus = 2^24 LSB
+        rms = float(np.sqrt((err.astype(np.float64) ** 2).mean()))
+        assert 2**22.5 < rms < 2**25, (g, rms)
+        assert np.abs(err).max() < 2**27, (g, int(np.abs(err).max()))
+
+
 def test_keyswitch_bit_exact(engine, oracle, okeys):
     rng = np.random.default_rng(15)
     for count in (1, 5, 32, 33, 70):      # ragged around the 32-ciphertext tile
