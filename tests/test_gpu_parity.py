@@ -141,6 +141,22 @@ def test_keyswitch_bit_exact(engine, oracle, okeys):
             assert np.array_equal(got[i], oracle.keyswitch(okeys, u[i])), (count, i)
 
 
+def test_keyswitch_preserves_the_phase(engine, keys):
+    """what src/test/lwekeyswitch_test.cpp:96-152 checks with a noiseless key, here with the real one and no oracle:
+    the phase of the switched sample under the LWE key equals the phase of the input under the extracted (TLWE) key
+    up to keyswitch noise (sigma 2^-15 per selected row, ~6144 rows) and the 2^-17 rounding of each coefficient"""
+    rng = np.random.default_rng(16)
+    u = rng.integers(-2**31, 2**31, (64, P.N + 1)).astype(np.int32)
+    out = engine.keyswitch_batch(u)
+    s_in, s_out = keys.tlwe_key.astype(np.int64), keys.lwe_key.astype(np.int64)
+    ph_in = u[:, P.N].astype(np.int64) - (u[:, :P.N].astype(np.int64) * s_in).sum(axis=1)
+    ph_out = out[:, P.n].astype(np.int64) - (out[:, :P.n].astype(np.int64) * s_out).sum(axis=1)
+    err = (ph_out - ph_in + 2**31) % 2**32 - 2**31
+    # predicted sigma: sqrt(6144) * 2^-15 = 2^-8.7 of the torus = 2^23.3 LSB
+    assert np.abs(err).max() < 2**26.5, int(np.abs(err).max())
+    assert 2**21.5 < np.sqrt((err.astype(np.float64) ** 2).mean()) < 2**24.5
+
+
 def test_bootstrap_bit_exact(engine, oracle, okeys, client, keys):
     bits = np.array([0, 1, 1, 0, 1], np.uint8)
     x = client.encrypt(keys, bits, seed=21)
