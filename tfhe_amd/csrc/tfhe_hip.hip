@@ -819,11 +819,15 @@ __global__ void k_ks_transpose(uint32_t *__restrict__ abarT, const int32_t *__re
     for (int r = ty; r < 32; r += 8) abarT[(size_t) (i0 + r) * Bp + g0 + tx] = tile[tx][r];
 }
 
-// grid (Bp/(32*MT), 5), block 256: wave w of block (x, y) owns 32*MT ciphertexts and coefficients
-// [32(4y+w), 32(4y+w)+32); all four limbs accumulate in one pass over i (A fragments built once per i)
+// grid (Bp/(32*MT), 5, S), block 256: wave w of block (x, y) owns 32*MT ciphertexts and coefficients
+// [32(4y+w), 32(4y+w)+32); all four limbs accumulate in one pass over i (A fragments built once per i).
+// Small batches cannot fill the chip with x * 5 blocks (a single gate: 5 blocks streaming 84 MB of key, 0.7 ms), so the
+// input coefficients i are split S ways (blockIdx.z) into `partial`, and k_ks_reduce adds the parts (integer sums:
+// any order gives the same bits).
 __global__ __launch_bounds__(256, 2) void k_keyswitch_mfma(const uint32_t *__restrict__ abarT, const int8_t *__restrict__ kl,
                                                         const int32_t *__restrict__ in, int32_t *__restrict__ out,
-                                                        long long B, long long Bp, const KsJob *__restrict__ kj) {
+                                                        long long B, long long Bp, const KsJob *__restrict__ kj,
+                                                        uint32_t *__restrict__ partial) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r32 = lane & 31, h = lane >> 5;
     const long long g0 = (long long) blockIdx.x * (32 * kKsMT);
@@ -837,8 +841,9 @@ __global__ __launch_bounds__(256, 2) void k_keyswitch_mfma(const uint32_t *__res
         for (int m = 0; m < kKsMT; m++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[l][m][r] = 0;
+    const int i_per = kN / (int) gridDim.z, i_lo = (int) blockIdx.z * i_per;
 #pragma unroll 2
-    for (int i = 0; i < kN; i++) {
+    for (int i = i_lo; i < i_lo + i_per; i++) {
         v4i_t b[4];
 #pragma unroll
         for (int l = 0; l < 4; l++) b[l] = bp[((size_t) i * 4 + l) * kKsQ * 2];
@@ -865,6 +870,10 @@ __global__ __launch_bounds__(256, 2) void k_keyswitch_mfma(const uint32_t *__res
             if (g < B) {
                 const uint32_t total = (uint32_t) acc[0][m][r] + ((uint32_t) acc[1][m][r] << 8) +
                                        ((uint32_t) acc[2][m][r] << 16) + ((uint32_t) acc[3][m][r] << 24);
+                if (partial) {
+                    partial[((size_t) blockIdx.z * Bp + g) * kCt + q] = total;
+                    continue;
+                }
                 uint32_t init = 0u;
                 long long orow = g;
                 if (kj) {
@@ -880,6 +889,31 @@ __global__ __launch_bounds__(256, 2) void k_keyswitch_mfma(const uint32_t *__res
                 out[orow * kCt + q] = (int32_t) (init - total);
             }
         }
+}
+
+// out = (0, b') - sum of the S partial sums (see k_keyswitch_mfma); one thread per (ciphertext, coefficient)
+__global__ __launch_bounds__(256) void k_ks_reduce(const uint32_t *__restrict__ partial, int S, const int32_t *__restrict__ in,
+                                                   int32_t *__restrict__ out, long long B, long long Bp,
+                                                   const KsJob *__restrict__ kj) {
+    const long long idx = (long long) blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * kCt) return;
+    const long long g = idx / kCt;
+    const int q = (int) (idx - g * kCt);
+    uint32_t total = 0u;
+    for (int sidx = 0; sidx < S; sidx++) total += partial[((size_t) sidx * Bp + g) * kCt + q];
+    uint32_t init = 0u;
+    long long orow = g;
+    if (kj) {
+        const KsJob j = kj[g];
+        orow = j.out;
+        if (q == kLwe) {
+            init = (uint32_t) in[(long long) j.e1 * kExt + kN] + (uint32_t) j.bconst;
+            if (j.e2 >= 0) init += (uint32_t) in[(long long) j.e2 * kExt + kN];
+        }
+    } else if (q == kLwe) {
+        init = (uint32_t) in[g * kExt + kN];
+    }
+    out[orow * kCt + q] = (int32_t) (init - total);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1171,7 +1205,7 @@ struct tfhe_hip_ctx {
     int8_t *kl = nullptr;    // [N][4][640][t][4] byte limbs (MFMA keyswitch)
     int ks_mfma = 1;
     bool have_keys = false;
-    DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc, abart, jobs_br, jobs_ks, jobs_lin;
+    DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc, abart, ks_part, jobs_br, jobs_ks, jobs_lin;
     std::vector<BrJob> h_br;
     std::vector<KsJob> h_ks;
     std::vector<int32_t> h_lin;
@@ -1254,8 +1288,21 @@ int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B,
         HIPCHK(c->abart.reserve((size_t) kN * Bp * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_ks_transpose, dim3((unsigned) (Bp / 32), kN / 32), dim3(256), 0, c->stream,
                            (uint32_t *) c->abart.p, d_in, B, Bp, kj);
-        hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) (Bp / (32 * kKsMT)), 5), dim3(256), 0, c->stream,
-                           (const uint32_t *) c->abart.p, (const int8_t *) c->kl, d_in, d_out, B, Bp, kj);
+        const long long xblocks = Bp / (32 * kKsMT);
+        int S = 1;
+        while (S < 16 && 5 * xblocks * S < 256) S *= 2;   // fill the 256 CUs
+        if (S == 1) {
+            hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) xblocks, 5), dim3(256), 0, c->stream,
+                               (const uint32_t *) c->abart.p, (const int8_t *) c->kl, d_in, d_out, B, Bp, kj,
+                               (uint32_t *) nullptr);
+        } else {
+            HIPCHK(c->ks_part.reserve((size_t) S * Bp * kCt * sizeof(uint32_t)));
+            hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) xblocks, 5, (unsigned) S), dim3(256), 0, c->stream,
+                               (const uint32_t *) c->abart.p, (const int8_t *) c->kl, d_in, d_out, B, Bp, kj,
+                               (uint32_t *) c->ks_part.p);
+            hipLaunchKernelGGL(k_ks_reduce, dim3((unsigned) ((B * kCt + 255) / 256)), dim3(256), 0, c->stream,
+                               (const uint32_t *) c->ks_part.p, S, d_in, d_out, B, Bp, kj);
+        }
     } else {
         dim3 grid((unsigned) ((B + kKsG - 1) / kKsG));
         hipLaunchKernelGGL(k_keyswitch, grid, dim3(192), 0, c->stream, d_in, c->ks, d_out, B);
@@ -1349,7 +1396,7 @@ void tfhe_hip_destroy(tfhe_hip_ctx *c) {
     if (!c) return;
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->in_a, &c->in_b, &c->in_c, &c->ext1, &c->ext2, &c->outb, &c->misc, &c->abart, &c->jobs_br, &c->jobs_ks,
+    for (DevBuf *b : {&c->in_a, &c->in_b, &c->in_c, &c->ext1, &c->ext2, &c->outb, &c->misc, &c->abart, &c->ks_part, &c->jobs_br, &c->jobs_ks,
                       &c->jobs_lin}) b->release();
     if (c->tw) (void) hipFree(c->tw);
     if (c->bk) (void) hipFree(c->bk);
