@@ -1255,7 +1255,9 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
     // waves per workgroup: 8 (two per SIMD) is the throughput shape.  Batches that cannot fill the chip that way run
     // with fewer waves per CU, which finish sooner (measured per wave: 8 per CU 16.4 ms, 4 per CU 10.5 ms, alone 8.8 ms)
     int waves = c->br_waves;
-    if (waves == 0) waves = A.B <= 256 ? (MODE == MODE_EXTMUL ? 1 : kCoopWaves) : A.B <= 1024 ? 4 : 8;
+    // (measured: 512 gates 7.7 ms as two rounds of the latency kernel against 9.6 ms with 4 waves per workgroup;
+    //  640 gates 11.4 ms against 9.6 ms)
+    if (waves == 0) waves = A.B <= 512 ? (MODE == MODE_EXTMUL ? (A.B <= 256 ? 1 : 4) : kCoopWaves) : A.B <= 1024 ? 4 : 8;
     if (waves == kCoopWaves && MODE != MODE_EXTMUL) {  // one workgroup per ciphertext (latency shape)
         HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate_coop<MODE == MODE_EXTMUL ? MODE_RAW : MODE>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kCoopLds));
