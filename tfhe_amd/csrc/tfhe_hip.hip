@@ -337,67 +337,67 @@ __device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int b
     spec_write(scratch, tmpa[1], lane);
     wave_sync();
     inv_phaseA(xa, twu);
+    prio_compute();
     spec_read(xb, scratch, lane);
     wave_sync();
-    prio_compute();
     prio_exchange();
     inv_t1_write<0>(scratch, xa, lane);
     wave_sync();
     inv_phaseA_lo(xb);
+    prio_compute();
     inv_t1_read<0>(wa, scratch, lane);
     wave_sync();
-    prio_compute();
     prio_exchange();
     inv_t1_write<1>(scratch, xa, lane);
     wave_sync();
     inv_phaseA_hi(xb, twu);
+    prio_compute();
     inv_t1_read<1>(wa, scratch, lane);
     wave_sync();
-    prio_compute();
     prio_exchange();
     inv_t1_write<0>(scratch, xb, lane);
     wave_sync();
     inv_level4(wa, twl);
+    prio_compute();
     inv_t1_read<0>(wb, scratch, lane);
     wave_sync();
-    prio_compute();
     prio_exchange();
     inv_t1_write<1>(scratch, xb, lane);
     wave_sync();
     inv_level5(wa, twl);
+    prio_compute();
     inv_t1_read<1>(wb, scratch, lane);
     wave_sync();
-    prio_compute();
     inv_level6(wa, twl);
     prio_exchange();
     inv_t2_write<0>(scratch, wa, lane);
     wave_sync();
     inv_level4(wb, twl);
+    prio_compute();
     inv_t2_read<0>(xa, scratch, lane);
     wave_sync();
-    prio_compute();
     prio_exchange();
     inv_t2_write<1>(scratch, wa, lane);
     wave_sync();
     inv_level5(wb, twl);
+    prio_compute();
     inv_t2_read<1>(xa, scratch, lane);
     wave_sync();
-    prio_compute();
     inv_level6(wb, twl);
     prio_exchange();
     inv_t2_write<0>(scratch, wb, lane);
     wave_sync();
     inv_level7(xa, twl);
+    prio_compute();
     inv_t2_read<0>(xb, scratch, lane);
     wave_sync();
-    prio_compute();
     prio_exchange();
     inv_t2_write<1>(scratch, wb, lane);
     wave_sync();
     inv_level8(xa, twl);
+    prio_compute();
     inv_t2_read<1>(xb, scratch, lane);
     wave_sync();
-    prio_compute();
     inv_level9(xa, twl);
     {
         int32_t res[16];
