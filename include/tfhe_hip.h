@@ -152,6 +152,21 @@ int tfhe_hip_negacyclic_mul2048_batch(tfhe_hip_ctx *ctx, int32_t *out, const int
 int tfhe_hip_negacyclic_mul2048_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_ipolys,
                                           const int32_t *d_tpolys, int64_t count);
 
+/* ---- client-side bulk operations (the part that parallelises) ------------------------------
+ * bootsSymEncrypt (tfhe_gate_bootstrapping.cpp:154-159: mu = +-1/8, noise 2^-15) of `count` bits under the secret
+ * LWE key (host int32[n], key bits 0/1), and lwePhase (lwe-functions.cpp:63-72; bootsSymDecrypt = phase > 0).
+ * The reference's generator (std::default_random_engine + normal_distribution) is not portable, so these reproduce
+ * the portable generator of tfhe_amd/csrc/client_keys.c bit for bit: sample i of a call is a function of
+ * (seed, first_index + i, bit, key) - equal to tfhe_client_encrypt for first_index = 0.  Parity with the reference
+ * itself is therefore semantic only (its own lwePhase decrypts these samples; tests/test_gpu_parity.py). */
+int tfhe_hip_encrypt_batch(tfhe_hip_ctx *ctx, int32_t *out, uint64_t seed, int64_t first_index, const int32_t *lwe_key,
+                           const uint8_t *bits, int64_t count);
+/* the same with the ciphertexts written to device memory (e.g. rows of a netlist pool); lwe_key and bits stay host */
+int tfhe_hip_encrypt_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, uint64_t seed, int64_t first_index,
+                               const int32_t *lwe_key, const uint8_t *bits, int64_t count);
+int tfhe_hip_phase_batch(tfhe_hip_ctx *ctx, int32_t *phases, const int32_t *lwe_key, const int32_t *samples,
+                         int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

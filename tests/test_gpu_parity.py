@@ -260,3 +260,37 @@ def test_every_launch_shape_gives_the_reference_ciphertexts(shape, keys, monkeyp
         assert np.array_equal(out, g["out"][int(Gate.MUX)]), shape
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_bulk_encrypt_and_phase_on_the_gpu(engine, client, keys, oracle):
+    """SURVEY 8(f) N3, the part that parallelises: bootsSymEncrypt (tfhe_gate_bootstrapping.cpp:154-159) and lwePhase
+    (lwe-functions.cpp:63-72) in bulk.  The ciphertexts equal the portable client's (tfhe_amd/csrc/client_keys.c) bit
+    for bit - the reference's own generator is not portable, so against the reference the parity is semantic: the
+    oracle's lwePhase (pinned to the reference's in tests/test_oracle_vs_ref.py) recovers +-1/8 with noise 2^-15."""
+    rng = np.random.default_rng(5)
+    for count in (1, 63, 64, 65, 1000, 4099):            # ragged tails of the 64-sample tiles
+        bits = rng.integers(0, 2, count).astype(np.uint8)
+        want = client.encrypt(keys, bits, seed=77)
+        got = engine.encrypt_batch(77, keys.lwe_key, bits)
+        assert np.array_equal(got, want), count
+    # first_index continues a stream: the second half of a batch can be produced by a second call
+    tail = engine.encrypt_batch(77, keys.lwe_key, bits[2000:], first_index=2000)
+    assert np.array_equal(tail, want[2000:])
+    ph = engine.phase_batch(keys.lwe_key, want)
+    for i in (0, 1, 64, 4098):
+        assert int(ph[i]) == oracle.phase(want[i], keys.lwe_key)
+    _, ph_client = client.decrypt(keys, want)
+    assert np.array_equal(ph, ph_client)
+    assert np.array_equal((ph > 0).astype(np.uint8), bits)
+    noise = ph.astype(np.int64) - np.where(bits == 1, 1 << 29, -(1 << 29))
+    assert 0.9 * 2 ** 17 < noise.std() < 1.1 * 2 ** 17 and abs(noise.mean()) < 2 ** 13
+    # device-resident output feeds a level directly: fresh ciphertexts born in the pool
+    d_pool = engine.dev_alloc(3 * (P.n + 1) * 4)
+    engine.encrypt_batch_dev(d_pool, 9, keys.lwe_key, np.array([1, 1], np.uint8))
+    engine.gate_level_dev(d_pool, 3, [[int(Gate.NAND), 2, 0, 1, -1]])
+    res = engine.from_dev(d_pool, (3, P.n + 1))
+    engine.dev_free(d_pool)
+    assert np.array_equal(res[:2], client.encrypt(keys, np.array([1, 1], np.uint8), seed=9))
+    assert int(engine.phase_batch(keys.lwe_key, res[2:])[0]) < 0
+    assert engine.encrypt_batch(1, keys.lwe_key, np.zeros(0, np.uint8)).shape == (0, P.n + 1)

@@ -1119,6 +1119,79 @@ __global__ __launch_bounds__(256) void k_combine2048(const int32_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// client-side bulk operations on the GPU (the part that parallelises): bootsSymEncrypt
+// (tfhe_gate_bootstrapping.cpp:154-159 = lweSymEncrypt, lwe-functions.cpp:44-56) and lwePhase (:63-72).
+// The reference draws from std::default_random_engine + normal_distribution, whose streams are not portable; these
+// kernels reproduce, bit for bit, the portable generator of tfhe_amd/csrc/client_keys.c (one xoshiro256** stream per
+// sample, Irwin-Hall(12) noise of standard deviation 2^-15), so a ciphertext is a function of (seed, index, bit, key).
+// ---------------------------------------------------------------------------------------------------------------
+struct ClientRng {
+    uint64_t s[4];
+};
+__device__ __forceinline__ uint64_t crng_splitmix(uint64_t &x) {
+    uint64_t z = (x += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ void crng_seed(ClientRng &r, uint64_t seed, uint64_t stream) {
+    uint64_t x = seed ^ (stream * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL);
+    for (int i = 0; i < 4; i++) r.s[i] = crng_splitmix(x);
+}
+__device__ __forceinline__ uint64_t crng_rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+__device__ __forceinline__ uint64_t crng_next(ClientRng &r) {  // xoshiro256**
+    const uint64_t res = crng_rotl(r.s[1] * 5, 7) * 9, t = r.s[1] << 17;
+    r.s[2] ^= r.s[0]; r.s[3] ^= r.s[1]; r.s[1] ^= r.s[2]; r.s[0] ^= r.s[3]; r.s[2] ^= t; r.s[3] = crng_rotl(r.s[3], 45);
+    return res;
+}
+__device__ __forceinline__ int32_t crng_gauss(ClientRng &r, int log2inv) {
+    int64_t s = 0;
+    for (int i = 0; i < 6; i++) {
+        const uint64_t w = crng_next(r);
+        s += (int64_t) (w >> 32) + (int64_t) (w & 0xffffffffu);
+    }
+    s -= (int64_t) 6 << 32;
+    return (int32_t) ((s + ((int64_t) 1 << (log2inv - 1))) >> log2inv);
+}
+// one thread per sample (the generator of a sample is sequential); the 630 mask words of 64 samples pass through LDS
+// so that the global stores are coalesced rows
+__global__ __launch_bounds__(64) void k_client_encrypt(uint64_t seed, const int32_t *__restrict__ key,
+                                                       const uint8_t *__restrict__ bits, long long first, long long count,
+                                                       int32_t *__restrict__ out) {
+    __shared__ int32_t tile[64][65];
+    const long long c0 = (long long) blockIdx.x * 64, c = c0 + threadIdx.x;
+    ClientRng r;
+    crng_seed(r, seed, 0x100000000ULL + (uint64_t) (first + c));
+    const bool live = c < count;
+    uint32_t b = live && bits[c] ? (1u << 29) : (0u - (1u << 29));
+    b += (uint32_t) crng_gauss(r, 15);
+    for (int q0 = 0; q0 < kLwe; q0 += 64) {
+        const int nq = kLwe - q0 < 64 ? kLwe - q0 : 64;
+        for (int q = 0; q < nq; q++) {
+            const int32_t a = (int32_t) (uint32_t) (crng_next(r) >> 32);
+            tile[threadIdx.x][q] = a;
+            b += (uint32_t) a * (uint32_t) key[q0 + q];
+        }
+        __syncthreads();
+        for (int row = 0; row < 64 && c0 + row < count; row++)
+            if ((int) threadIdx.x < nq) out[(c0 + row) * kCt + q0 + threadIdx.x] = tile[row][threadIdx.x];
+        __syncthreads();
+    }
+    if (live) out[c * kCt + kLwe] = (int32_t) b;
+}
+// lwePhase: b - <a, s>; one wave per sample
+__global__ __launch_bounds__(256) void k_client_phase(const int32_t *__restrict__ key, const int32_t *__restrict__ ct,
+                                                      long long count, int32_t *__restrict__ phases) {
+    const long long c = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= count) return;
+    uint32_t acc = 0;
+    for (int q = lane; q < kLwe; q += 64) acc += (uint32_t) ct[c * kCt + q] * (uint32_t) key[q];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) phases[c] = (int32_t) ((uint32_t) ct[c * kCt + kLwe] - acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 thread_local std::string g_err;
@@ -1797,6 +1870,49 @@ int tfhe_hip_negacyclic_mul2048_batch(tfhe_hip_ctx *c, int32_t *out, const int32
                                                       (const int32_t *) c->in_b.p, count))
         return r;
     return d2h(c, out, c->outb.p, pb);
+}
+
+// ---- client-side bulk operations --------------------------------------------------------------
+int tfhe_hip_encrypt_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, uint64_t seed, int64_t first_index,
+                               const int32_t *lwe_key, const uint8_t *bits, int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || first_index < 0 || (count > 0 && (!d_out || !lwe_key || !bits)))
+        return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    HIPCHK(c->misc.reserve(kLwe * sizeof(int32_t) + (size_t) count));
+    int32_t *d_key = (int32_t *) c->misc.p;
+    uint8_t *d_bits = (uint8_t *) (d_key + kLwe);
+    HIPCHK(hipMemcpyAsync(d_key, lwe_key, kLwe * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_bits, bits, (size_t) count, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_client_encrypt, dim3((unsigned) ((count + 63) / 64)), dim3(64), 0, c->stream, seed,
+                       (const int32_t *) d_key, (const uint8_t *) d_bits, (long long) first_index, (long long) count, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));  // misc is reused by other calls
+    return TFHE_HIP_OK;
+}
+int tfhe_hip_encrypt_batch(tfhe_hip_ctx *c, int32_t *out, uint64_t seed, int64_t first_index, const int32_t *lwe_key,
+                           const uint8_t *bits, int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || (count > 0 && !out)) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    const size_t ob = (size_t) count * kCt * sizeof(int32_t);
+    HIPCHK(c->outb.reserve(ob));
+    if (int r = tfhe_hip_encrypt_batch_dev(c, (int32_t *) c->outb.p, seed, first_index, lwe_key, bits, count)) return r;
+    return d2h(c, out, c->outb.p, ob);
+}
+int tfhe_hip_phase_batch(tfhe_hip_ctx *c, int32_t *phases, const int32_t *lwe_key, const int32_t *samples, int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || (count > 0 && (!phases || !lwe_key || !samples))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    const size_t ib = (size_t) count * kCt * sizeof(int32_t);
+    if (int r = h2d(c, c->in_a, samples, ib)) return r;
+    HIPCHK(c->misc.reserve(kLwe * sizeof(int32_t)));
+    HIPCHK(hipMemcpyAsync(c->misc.p, lwe_key, kLwe * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c->outb.reserve((size_t) count * sizeof(int32_t)));
+    hipLaunchKernelGGL(k_client_phase, dim3((unsigned) ((count + 3) / 4)), dim3(256), 0, c->stream,
+                       (const int32_t *) c->misc.p, (const int32_t *) c->in_a.p, (long long) count, (int32_t *) c->outb.p);
+    HIPCHK(hipGetLastError());
+    return d2h(c, phases, c->outb.p, (size_t) count * sizeof(int32_t));
 }
 
 // ---- netlist level on a device-resident ciphertext pool ---------------------------------------

@@ -56,6 +56,7 @@ EXPORTS = [
     "tfhe_hip_negacyclic_mul_batch", "tfhe_hip_negacyclic_mul_batch_dev", "tfhe_hip_gate_level_dev",
     "tfhe_hip_dev_alloc", "tfhe_hip_dev_free", "tfhe_hip_copy_to_dev", "tfhe_hip_copy_from_dev",
     "tfhe_hip_negacyclic_mul2048_batch", "tfhe_hip_negacyclic_mul2048_batch_dev",
+    "tfhe_hip_encrypt_batch", "tfhe_hip_encrypt_batch_dev", "tfhe_hip_phase_batch",
 ]
 
 
@@ -221,6 +222,30 @@ class Engine:
         br, ks = ctypes.c_float(), ctypes.c_float()
         self._chk(self.lib.tfhe_hip_last_kernel_ms(self.ctx, ctypes.byref(br), ctypes.byref(ks)), "last_kernel_ms")
         return br.value, ks.value
+
+    # ---- client-side bulk operations ----
+    def encrypt_batch(self, seed, lwe_key, bits, first_index=0):
+        key = _i32(lwe_key, (PARAMS.n,)).reshape(-1)
+        b = np.ascontiguousarray(bits, dtype=np.uint8).reshape(-1)
+        out = np.empty((b.shape[0], PARAMS.n + 1), dtype=np.int32)
+        self._chk(self.lib.tfhe_hip_encrypt_batch(self.ctx, _p(out), ctypes.c_uint64(seed), ctypes.c_int64(first_index),
+                                                  _p(key), _p(b), ctypes.c_int64(b.shape[0])), "encrypt_batch")
+        return out
+
+    def encrypt_batch_dev(self, out, seed, lwe_key, bits, first_index=0):
+        key = _i32(lwe_key, (PARAMS.n,)).reshape(-1)
+        b = np.ascontiguousarray(bits, dtype=np.uint8).reshape(-1)
+        self._chk(self.lib.tfhe_hip_encrypt_batch_dev(self.ctx, self._dptr(out), ctypes.c_uint64(seed),
+                                                      ctypes.c_int64(first_index), _p(key), _p(b),
+                                                      ctypes.c_int64(b.shape[0])), "encrypt_batch_dev")
+
+    def phase_batch(self, lwe_key, samples):
+        key = _i32(lwe_key, (PARAMS.n,)).reshape(-1)
+        s = _i32(samples, (PARAMS.n + 1,))
+        out = np.empty(s.shape[0], dtype=np.int32)
+        self._chk(self.lib.tfhe_hip_phase_batch(self.ctx, _p(out), _p(key), _p(s), ctypes.c_int64(s.shape[0])),
+                  "phase_batch")
+        return out
 
     # ---- stages ----
     def blind_rotate_batch(self, acc, bara):
