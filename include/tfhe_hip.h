@@ -164,6 +164,14 @@ int tfhe_hip_encrypt_batch(tfhe_hip_ctx *ctx, int32_t *out, uint64_t seed, int64
 /* the same with the ciphertexts written to device memory (e.g. rows of a netlist pool); lwe_key and bits stay host */
 int tfhe_hip_encrypt_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, uint64_t seed, int64_t first_index,
                                const int32_t *lwe_key, const uint8_t *bits, int64_t count);
+/* tfhe_createLweBootstrappingKey (lwe-bootstrapping-functions.cpp:185-217) on the GPU: draws bk[i] = TGSW(s_i) for
+ * the given secret keys (host int32[n], int32[N], bits 0/1) with the portable generator (stream 0x10000 + i of `seed`,
+ * as tfhe_client_keygen), transforms it and installs it with the keyswitch key `ks` (host, layout of
+ * tfhe_hip_load_keys_coef; its 24,576 short samples come from one sequential stream and take 30 ms on one CPU core,
+ * so they stay with the client library).  bk_coef_out (host int32[n][6][2][N], may be NULL) receives the coefficient
+ * form, equal to tfhe_client_keygen's bit for bit.  The secret keys are wiped from device memory before returning. */
+int tfhe_hip_keygen_bk(tfhe_hip_ctx *ctx, uint64_t seed, const int32_t *lwe_key, const int32_t *tlwe_key,
+                       const int32_t *ks, int32_t *bk_coef_out);
 int tfhe_hip_phase_batch(tfhe_hip_ctx *ctx, int32_t *phases, const int32_t *lwe_key, const int32_t *samples,
                          int64_t count);
 

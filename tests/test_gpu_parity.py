@@ -294,3 +294,31 @@ def test_bulk_encrypt_and_phase_on_the_gpu(engine, client, keys, oracle):
     assert np.array_equal(res[:2], client.encrypt(keys, np.array([1, 1], np.uint8), seed=9))
     assert int(engine.phase_batch(keys.lwe_key, res[2:])[0]) < 0
     assert engine.encrypt_batch(1, keys.lwe_key, np.zeros(0, np.uint8)).shape == (0, P.n + 1)
+
+
+@pytest.mark.gpu
+def test_bootstrapping_key_generated_on_the_gpu(client, keys, engine):
+    """tfhe_createLweBootstrappingKey (lwe-bootstrapping-functions.cpp:185-217) on the GPU.  The
+    coefficient-form key equals the portable client's for the same seed bit for bit (3,780 TLWE rows), the transformed
+    key installed on the device equals the one the session engine derived from the client's key, and a context keyed
+    this way evaluates gates to the same ciphertexts."""
+    import time
+    from tfhe_amd import Engine
+    e2 = Engine(0)
+    try:
+        t0 = time.perf_counter()
+        coef = e2.keygen_bk(42, keys.lwe_key, keys.tlwe_key, keys.ks, want_coef=True)
+        dt = time.perf_counter() - t0
+        assert np.array_equal(coef, np.asarray(keys.bk_coef).reshape(coef.shape))
+        assert np.array_equal(e2.get_bkfft().view(np.int64), engine.get_bkfft().view(np.int64))
+        bits = np.random.default_rng(3).integers(0, 2, (2, 64)).astype(np.uint8)
+        a, b = client.encrypt(keys, bits[0], seed=31), client.encrypt(keys, bits[1], seed=32)
+        assert np.array_equal(e2.gate_batch(Gate.XOR, a, b), engine.gate_batch(Gate.XOR, a, b))
+        # a different seed gives a different key that still bootstraps correctly (same secret keys, fresh randomness)
+        e2.keygen_bk(43, keys.lwe_key, keys.tlwe_key, keys.ks)
+        out = e2.gate_batch(Gate.XOR, a, b)
+        assert not np.array_equal(out, engine.gate_batch(Gate.XOR, a, b))
+        assert np.array_equal(client.decrypt(keys, out)[0], bits[0] ^ bits[1])
+        print("keygen_bk %.3f s" % dt)
+    finally:
+        e2.close()

@@ -1191,6 +1191,51 @@ __global__ __launch_bounds__(256) void k_client_phase(const int32_t *__restrict_
     if (lane == 0) phases[c] = (int32_t) ((uint32_t) ct[c * kCt + kLwe] - acc);
 }
 
+// bootstrapping-key generation (tfhe_createLweBootstrappingKey, lwe-bootstrapping-functions.cpp:185-217: bk[i] =
+// TGSW(s_i) under the TLWE key, tGswSymEncryptInt = 6 TLWE zero-encryptions + s_i * H, tgsw-functions.cpp:100-133),
+// bit-identical to bk_worker of client_keys.c.  Stage 1: one thread per key bit i draws its stream (noise then mask
+// of each row, sequential by construction).  Stage 2: one workgroup per row adds mask * tlwe_key in Z[X]/(X^N+1)
+// (torusPolynomialAddMulR at tlwe-functions.cpp:35) - exact mod 2^32 in any summation order - and the gadget term.
+__global__ __launch_bounds__(64) void k_client_bk_draw(uint64_t seed, int32_t *__restrict__ bk_coef) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= kLwe) return;
+    ClientRng r;
+    crng_seed(r, seed, 0x10000ULL + (uint64_t) i);
+    for (int p = 0; p < kKpl; p++) {
+        int32_t *a = bk_coef + (((size_t) i * kKpl + p) * 2 + 0) * kN, *b = a + kN;
+        for (int q = 0; q < kN; q++) b[q] = crng_gauss(r, 25);
+        for (int q = 0; q < kN; q++) a[q] = (int32_t) (uint32_t) (crng_next(r) >> 32);
+    }
+}
+__global__ __launch_bounds__(256) void k_client_bk_mask(const int32_t *__restrict__ lwe_key, const int32_t *__restrict__ tlwe_key,
+                                                        int32_t *__restrict__ bk_coef) {
+    __shared__ uint32_t sa[kN];
+    __shared__ uint8_t sk[kN];
+    const int row = blockIdx.x, i = row / kKpl, p = row % kKpl, x = threadIdx.x;
+    int32_t *a = bk_coef + ((size_t) row * 2 + 0) * kN, *b = a + kN;
+    for (int q = x; q < kN; q += 256) {
+        sa[q] = (uint32_t) a[q];
+        sk[q] = (uint8_t) (tlwe_key[q] != 0);
+    }
+    __syncthreads();
+    uint32_t acc[4];
+    for (int u = 0; u < 4; u++) acc[u] = (uint32_t) b[x + 256 * u];
+    for (int j = 0; j < kN; j++) {
+        if (!sk[j]) continue;  // uniform over the workgroup
+        for (int u = 0; u < 4; u++) {
+            const int d = x + 256 * u - j;
+            if (d >= 0) acc[u] += sa[d];
+            else acc[u] -= sa[d + kN];
+        }
+    }
+    const uint32_t h = (uint32_t) lwe_key[i] * (1u << (32 - (p % kL + 1) * kBgbit));
+    if (x == 0) {
+        if (p / kL == 0) a[0] = (int32_t) (sa[0] + h);
+        else acc[0] += h;
+    }
+    for (int u = 0; u < 4; u++) b[x + 256 * u] = (int32_t) acc[u];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -1493,15 +1538,9 @@ int tfhe_hip_sync(tfhe_hip_ctx *c) {
     return TFHE_HIP_OK;
 }
 
-int tfhe_hip_load_keys_coef(tfhe_hip_ctx *c, const int32_t *bk_coef, const int32_t *ks) {
-    if (int r = check_ctx(c, false)) return r;
-    if (!bk_coef || !ks) return fail(TFHE_HIP_ERR_ARG, "null key pointer");
-    c->have_keys = false;
+// the coefficient-form bootstrapping key sits in c->misc: transform it, then upload the keyswitch key
+static int keys_from_coef_in_misc(tfhe_hip_ctx *c, const int32_t *ks) {
     const int npoly = kLwe * kKpl * 2;
-    const size_t coef_bytes = (size_t) npoly * kN * sizeof(int32_t);
-    if (!c->bk) HIPCHK(hipMalloc((void **) &c->bk, kBkBytes));
-    HIPCHK(c->misc.reserve(coef_bytes));
-    HIPCHK(hipMemcpyAsync(c->misc.p, bk_coef, coef_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipFuncSetAttribute((const void *) k_bk_convert, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
     hipLaunchKernelGGL(k_bk_convert, dim3((npoly + 3) / 4), dim3(256), kFftLds, c->stream, (const int32_t *) c->misc.p,
                        c->bk, (const c64 *) c->tw, c->ka, npoly);
@@ -1512,6 +1551,41 @@ int tfhe_hip_load_keys_coef(tfhe_hip_ctx *c, const int32_t *bk_coef, const int32
     c->misc.release();
     c->have_keys = true;
     return TFHE_HIP_OK;
+}
+
+int tfhe_hip_load_keys_coef(tfhe_hip_ctx *c, const int32_t *bk_coef, const int32_t *ks) {
+    if (int r = check_ctx(c, false)) return r;
+    if (!bk_coef || !ks) return fail(TFHE_HIP_ERR_ARG, "null key pointer");
+    c->have_keys = false;
+    const int npoly = kLwe * kKpl * 2;
+    const size_t coef_bytes = (size_t) npoly * kN * sizeof(int32_t);
+    if (!c->bk) HIPCHK(hipMalloc((void **) &c->bk, kBkBytes));
+    HIPCHK(c->misc.reserve(coef_bytes));
+    HIPCHK(hipMemcpyAsync(c->misc.p, bk_coef, coef_bytes, hipMemcpyHostToDevice, c->stream));
+    return keys_from_coef_in_misc(c, ks);
+}
+
+int tfhe_hip_keygen_bk(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key, const int32_t *tlwe_key, const int32_t *ks,
+                       int32_t *bk_coef_out) {
+    if (int r = check_ctx(c, false)) return r;
+    if (!lwe_key || !tlwe_key || !ks) return fail(TFHE_HIP_ERR_ARG, "null key pointer");
+    c->have_keys = false;
+    const size_t coef_bytes = (size_t) kLwe * kKpl * 2 * kN * sizeof(int32_t);
+    if (!c->bk) HIPCHK(hipMalloc((void **) &c->bk, kBkBytes));
+    HIPCHK(c->misc.reserve(coef_bytes));
+    HIPCHK(c->abart.reserve((kLwe + kN) * sizeof(int32_t)));
+    int32_t *d_lwe = (int32_t *) c->abart.p, *d_tlwe = d_lwe + kLwe;
+    HIPCHK(hipMemcpyAsync(d_lwe, lwe_key, kLwe * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_tlwe, tlwe_key, kN * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_client_bk_draw, dim3((kLwe + 63) / 64), dim3(64), 0, c->stream, seed, (int32_t *) c->misc.p);
+    hipLaunchKernelGGL(k_client_bk_mask, dim3(kLwe * kKpl), dim3(256), 0, c->stream, (const int32_t *) d_lwe,
+                       (const int32_t *) d_tlwe, (int32_t *) c->misc.p);
+    HIPCHK(hipGetLastError());
+    if (bk_coef_out) HIPCHK(hipMemcpyAsync(bk_coef_out, c->misc.p, coef_bytes, hipMemcpyDeviceToHost, c->stream));
+    const int r = keys_from_coef_in_misc(c, ks);
+    hipMemsetAsync(c->abart.p, 0, (kLwe + kN) * sizeof(int32_t), c->stream);  // the secret keys do not stay on the device
+    hipStreamSynchronize(c->stream);
+    return r;
 }
 
 int tfhe_hip_load_keys_fft(tfhe_hip_ctx *c, const double *bkfft, const int32_t *ks) {

@@ -56,7 +56,7 @@ EXPORTS = [
     "tfhe_hip_negacyclic_mul_batch", "tfhe_hip_negacyclic_mul_batch_dev", "tfhe_hip_gate_level_dev",
     "tfhe_hip_dev_alloc", "tfhe_hip_dev_free", "tfhe_hip_copy_to_dev", "tfhe_hip_copy_from_dev",
     "tfhe_hip_negacyclic_mul2048_batch", "tfhe_hip_negacyclic_mul2048_batch_dev",
-    "tfhe_hip_encrypt_batch", "tfhe_hip_encrypt_batch_dev", "tfhe_hip_phase_batch",
+    "tfhe_hip_encrypt_batch", "tfhe_hip_encrypt_batch_dev", "tfhe_hip_phase_batch", "tfhe_hip_keygen_bk",
 ]
 
 
@@ -238,6 +238,16 @@ class Engine:
         self._chk(self.lib.tfhe_hip_encrypt_batch_dev(self.ctx, self._dptr(out), ctypes.c_uint64(seed),
                                                       ctypes.c_int64(first_index), _p(key), _p(b),
                                                       ctypes.c_int64(b.shape[0])), "encrypt_batch_dev")
+
+    def keygen_bk(self, seed, lwe_key, tlwe_key, ks, want_coef=False):
+        """draw, transform and install the bootstrapping key on the device; returns its coefficient form if asked"""
+        lk = _i32(lwe_key, (PARAMS.n,)).reshape(-1)
+        tk = _i32(tlwe_key, (PARAMS.N,)).reshape(-1)
+        ks = np.ascontiguousarray(ks, dtype=np.int32)
+        out = np.empty((PARAMS.n, 6, 2, PARAMS.N), np.int32) if want_coef else None
+        self._chk(self.lib.tfhe_hip_keygen_bk(self.ctx, ctypes.c_uint64(seed), _p(lk), _p(tk), _p(ks),
+                                              _p(out) if want_coef else None), "keygen_bk")
+        return out
 
     def phase_batch(self, lwe_key, samples):
         key = _i32(lwe_key, (PARAMS.n,)).reshape(-1)
