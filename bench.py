@@ -32,8 +32,9 @@ FLOP_PER_BOOTSTRAP = 162570240.0   # 630 x (8 x 26,112 + 49,152)
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak (vendor spec)
 
 
-def cpu_baseline(keys, ca, cb, expect_bits, client):
-    """times NAND gates on the host cores: the reference build if it travelled here, else the oracle port"""
+def cpu_baseline(keys, ca, cb, expect_bits, client, params=None):
+    """times NAND gates on the host cores: the reference build if it travelled here, else the oracle port (the 80-bit
+    set: always the port - the reference's hot path hard-codes the default set)"""
     import ctypes
     from tests.oracle_lib import Oracle, REF_SO, P
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
@@ -43,7 +44,7 @@ def cpu_baseline(keys, ca, cb, expect_bits, client):
     a, b = np.ascontiguousarray(ca[:count]), np.ascontiguousarray(cb[:count])
     out = np.zeros_like(a)
     kind = "port"
-    if os.path.exists(REF_SO):
+    if os.path.exists(REF_SO) and (params is None or params.lam == 128):
         try:
             ref = ctypes.CDLL(REF_SO)
             ref.ref_set_keys(P(keys.lwe_key), P(keys.tlwe_key), P(keys.bk_coef), P(keys.ks))
@@ -54,7 +55,7 @@ def cpu_baseline(keys, ca, cb, expect_bits, client):
         except OSError:
             kind = "port"
     if kind == "port":
-        orc = Oracle()
+        orc = Oracle(params)
         ok = orc.keys_from_coef(keys.bk_coef, keys.ks)
         t0 = time.perf_counter()
         out = orc.gate_batch(ok, 0, a, b, nthreads=threads)
@@ -185,11 +186,16 @@ def main():
                     help="nand: BASELINE configs[1] (default, the headline); adder: configs[3] levelized 32-bit adders; "
                          "mux / fft: configs[4] side benches")
     ap.add_argument("--instances", type=int, default=4096, help="adder workload: independent adder instances")
+    ap.add_argument("--param-set", type=int, default=128, choices=[128, 80],
+                    help="128: the default set, BASELINE's metric; 80: the 80-bit set (nand workload only, side bench)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from tfhe_amd import Client, Engine, Gate, PARAMS as PR
+    from tfhe_amd import Client, Engine, Gate, PARAMS, PARAMS_80
+    PR = PARAMS if args.param_set == 128 else PARAMS_80
+    if args.param_set != 128 and args.workload != "nand":
+        raise SystemExit("--param-set 80 is measured on the nand workload only")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -210,12 +216,12 @@ def main():
     if args.workload != "nand":
         return side_bench(args, torch, dev, rank, world)
 
-    client = Client()
+    client = Client(PR)
     # ---- keys: generated once (rank 0), replicated to every GPU by an RCCL broadcast -------------------------
     from tfhe_amd.parallel import broadcast_keys
     cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")   # collective tensors
-    keys = broadcast_keys(client.keygen(42) if rank == 0 else None, device=cdev)
-    eng = Engine(dev_index)
+    keys = broadcast_keys(client.keygen(42) if rank == 0 else None, device=cdev, params=PR)
+    eng = Engine(dev_index, PR)
     eng.load_keys_coef(keys.bk_coef, keys.ks)
 
     # ---- synthetic inputs: fresh encryptions of iid random bits, resident in HBM -----------------------------
@@ -279,7 +285,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, cpu_out = cpu_baseline(keys, ca, cb, expect, client)
+        cpu, cpu_out = cpu_baseline(keys, ca, cb, expect, client, PR)
         # the GPU's ciphertexts are the CPU path's ciphertexts, bit for bit
         if not np.array_equal(cpu_out, got[:cpu_out.shape[0]]):
             raise RuntimeError("GPU ciphertexts differ from the CPU path's")
@@ -290,18 +296,23 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
         br_avg = float(np.mean(br_ms))
-        achieved = FLOP_PER_BOOTSTRAP * B / (br_avg * 1e-3) / 1e12
+        # per CMux: kpl + 2 transforms of 26,112 flop and kpl x 2 x 512 complex multiply-adds of 8 flop
+        flop_per_bootstrap = PR.n * ((PR.kpl + 2) * 26112.0 + PR.kpl * 2 * 512 * 8.0)
+        assert PR.lam != 128 or flop_per_bootstrap == FLOP_PER_BOOTSTRAP
+        achieved = flop_per_bootstrap * B / (br_avg * 1e-3) / 1e12
         traffic = None
         tr_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr_file):
+        if os.path.exists(tr_file) and PR.lam == 128:
             with open(tr_file) as f:
                 traffic = json.load(f).get("k_blind_rotate_hbm_bytes_per_launch")
         line = {
-            "metric": "bootstrapped gates/sec (n=630 N=1024 l=3 Bgbit=7, bootsNAND)", "value": value,
+            "metric": "bootstrapped gates/sec (n=%d N=1024 l=%d Bgbit=%d, bootsNAND)" % (PR.n, PR.l, PR.Bgbit),
+            "value": value,
             "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "batch of %d independent bootsNAND gates per GPU (BASELINE configs[1])" % B,
+            "config": {"workload": "batch of %d independent bootsNAND gates per GPU (%s)"
+                                   % (B, "BASELINE configs[1]" if PR.lam == 128 else "80-bit parameter set, side bench"),
                        "gates_per_gpu_per_step": B, "parallelism": "gates sharded over %d GPU(s), keys replicated" % world,
                        "outputs_decrypt_correctly": True},
             "per_gate_latency_ms": lat_ms,
@@ -312,7 +323,7 @@ def main():
                          "achieved": achieved,
                          "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "flop_per_launch": FLOP_PER_BOOTSTRAP * B, "launch_ms": br_avg},
+                         "flop_per_launch": flop_per_bootstrap * B, "launch_ms": br_avg},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -34,9 +34,27 @@
 extern "C" {
 #endif
 
+/* The parameter set is fixed at build time; one library per set (tfhe_gate_bootstrapping.cpp:23-75):
+ *   libtfhe_hip.so     TFHE_HIP_LAMBDA 128 (default): n = 630, l = 3, Bgbit = 7
+ *   libtfhe_hip_80.so  TFHE_HIP_LAMBDA 80:            n = 500, l = 2, Bgbit = 10
+ * N = 1024, k = 1 and the keyswitch decomposition (t = 8, base 4) are common.  A host compiled against this header
+ * defines TFHE_HIP_LAMBDA to match the library it links and can check with tfhe_hip_param_set(). */
+#ifndef TFHE_HIP_LAMBDA
+#define TFHE_HIP_LAMBDA 128
+#endif
+#if TFHE_HIP_LAMBDA == 128
 #define TFHE_HIP_n 630
+#define TFHE_HIP_L 3
+#define TFHE_HIP_BGBIT 7
+#elif TFHE_HIP_LAMBDA == 80
+#define TFHE_HIP_n 500
+#define TFHE_HIP_L 2
+#define TFHE_HIP_BGBIT 10
+#else
+#error "TFHE_HIP_LAMBDA must be 128 or 80"
+#endif
 #define TFHE_HIP_N 1024
-#define TFHE_HIP_KPL 6
+#define TFHE_HIP_KPL (2 * TFHE_HIP_L)
 #define TFHE_HIP_KS_T 8
 #define TFHE_HIP_KS_BASE 4
 
@@ -151,6 +169,9 @@ int tfhe_hip_negacyclic_mul2048_batch(tfhe_hip_ctx *ctx, int32_t *out, const int
                                       int64_t count);
 int tfhe_hip_negacyclic_mul2048_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_ipolys,
                                           const int32_t *d_tpolys, int64_t count);
+
+/* the parameter set this library was built for: out = {lambda, n, N, k, l, Bgbit, ks_t, ks_basebit} */
+void tfhe_hip_param_set(int32_t out[8]);
 
 /* ---- client-side bulk operations (the part that parallelises) ------------------------------
  * bootsSymEncrypt (tfhe_gate_bootstrapping.cpp:154-159: mu = +-1/8, noise 2^-15) of `count` bits under the secret

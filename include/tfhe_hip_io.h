@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TFHE_HIP_IO_SAMPLE_BYTES 2536 /* 4 + 4*(630+1) + 8 */
+#define TFHE_HIP_IO_SAMPLE_BYTES (4 + 4 * (TFHE_HIP_n + 1) + 8) /* 2536 for n = 630 */
 
 /* ---- parameter set: new_tfheGateBootstrappingParameterSet_fromFile / export_..._toFile (tfhe_io.cpp:1050-1060) ---- */
 /* checks that buf starts with the default parameter set; *consumed = bytes of the text sections */

@@ -211,12 +211,13 @@ void oracle_TorusPolynomial_fft(int32_t *out, const double *spec) {
 
 /* src/libtfhe/tgsw-functions.cpp:297-331 with the constants of src/include/tfhe_core.h:20-24 */
 void oracle_decompH(int32_t *out, const int32_t *poly) {
-    const uint32_t offset = 2164391936u; /* = 64*(2^25 + 2^18 + 2^11), tgsw.cpp:21-27 */
+    uint32_t offset = 0; /* sum of Bg/2 * 2^(32 - p*Bgbit), tgsw.cpp:21-27; 2164391936 for the default set */
+    for (int p = 1; p <= ORC_l; p++) offset += (uint32_t) (1 << (ORC_Bgbit - 1)) << (32 - p * ORC_Bgbit);
     for (int p = 0; p < ORC_l; p++) {
         int shift = 32 - (p + 1) * ORC_Bgbit;
         for (int j = 0; j < N; j++) {
             uint32_t u = (uint32_t) poly[j] + offset;
-            out[p * N + j] = (int32_t) ((u >> shift) & 127u) - 64;
+            out[p * N + j] = (int32_t) ((u >> shift) & ((1u << ORC_Bgbit) - 1)) - (1 << (ORC_Bgbit - 1));
         }
     }
 }

@@ -8,7 +8,18 @@
 extern "C" {
 #endif
 
-enum { ORC_n = 630, ORC_N = 1024, ORC_2N = 2048, ORC_Ns2 = 512, ORC_k = 1, ORC_l = 3, ORC_kpl = 6, ORC_Bgbit = 7,
+/* liboracle.so: the default 128-bit set (tfhe_gate_bootstrapping.cpp:51-75; the one this reference hard-codes in
+ * src/include/tfhe_core.h:13-24).  liboracle_80.so (-DORC_LAMBDA=80): the 80-bit set of :23-48 - PARITY UNPINNED,
+ * the reference's own hot path cannot run that set (its n, l, Bgbit are compile-time constants). */
+#ifndef ORC_LAMBDA
+#define ORC_LAMBDA 128
+#endif
+#if ORC_LAMBDA == 128
+enum { ORC_n = 630, ORC_l = 3, ORC_Bgbit = 7 };
+#else
+enum { ORC_n = 500, ORC_l = 2, ORC_Bgbit = 10 };
+#endif
+enum { ORC_N = 1024, ORC_2N = 2048, ORC_Ns2 = 512, ORC_k = 1, ORC_kpl = 2 * ORC_l,
        ORC_ks_t = 8, ORC_ks_basebit = 2, ORC_ks_base = 4 };
 
 /* gate ids shared with include/tfhe_hip.h */

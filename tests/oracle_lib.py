@@ -28,8 +28,12 @@ def i32(a):
 
 
 class Oracle:
-    def __init__(self):
-        self.lib = ctypes.CDLL(ORACLE_SO)
+    def __init__(self, params=None):
+        """params: a tfhe_amd.ParamSet; None = the default 128-bit set.  The 80-bit oracle is PARITY UNPINNED (the
+        reference hard-codes the default set in its hot path, src/include/tfhe_core.h:13-24)."""
+        self.n, self.kpl, self.l = (630, 6, 3) if params is None else (params.n, params.kpl, params.l)
+        so = ORACLE_SO if params is None or params.lam == 128 else ORACLE_SO.replace(".so", "%s.so" % params.suffix)
+        self.lib = ctypes.CDLL(so)
         self.lib.oracle_keys_from_coef.restype = ctypes.c_void_p
         self.lib.oracle_keys_from_fft.restype = ctypes.c_void_p
         self.lib.oracle_trig_table_hash.restype = ctypes.c_uint64
@@ -42,7 +46,7 @@ class Oracle:
         return ctypes.c_void_p(self.lib.oracle_keys_from_fft(P(np.ascontiguousarray(bkfft, np.float64)), P(i32(ks))))
 
     def bkfft(self, k):
-        out = np.empty((n, KPL, 2, N // 2, 2), np.float64)
+        out = np.empty((self.n, self.kpl, 2, N // 2, 2), np.float64)
         self.lib.oracle_keys_get_bkfft(k, P(out))
         return out
 
@@ -63,7 +67,7 @@ class Oracle:
         return out
 
     def decomp(self, poly):
-        out = np.empty((3, N), np.int32)
+        out = np.empty((self.l, N), np.int32)
         self.lib.oracle_decompH(P(out), P(i32(poly)))
         return out
 
@@ -121,17 +125,17 @@ class Oracle:
         return out
 
     def keyswitch(self, k, u):
-        out = np.empty(n + 1, np.int32)
+        out = np.empty(self.n + 1, np.int32)
         self.lib.oracle_keyswitch(k, P(out), P(i32(u)))
         return out
 
     def bootstrap(self, k, x, mu=1 << 29):
-        out = np.empty(n + 1, np.int32)
+        out = np.empty(self.n + 1, np.int32)
         self.lib.oracle_bootstrap(k, P(out), P(i32(x)), ctypes.c_int32(mu))
         return out
 
     def gate(self, k, gate, a=None, b=None, c=None):
-        out = np.empty(n + 1, np.int32)
+        out = np.empty(self.n + 1, np.int32)
         self.lib.oracle_gate(k, ctypes.c_int32(int(gate)), P(out), P(i32(a)), P(i32(b)), P(i32(c)))
         return out
 
@@ -139,7 +143,7 @@ class Oracle:
         a, b, c = i32(a), i32(b), i32(c)
         if count is None:
             count = a.shape[0]
-        out = np.empty((count, n + 1), np.int32)
+        out = np.empty((count, self.n + 1), np.int32)
         self.lib.oracle_gate_batch(k, ctypes.c_int32(int(gate)), P(out), P(a), P(b), P(c), ctypes.c_int64(count),
                                    ctypes.c_int32(nthreads))
         return out

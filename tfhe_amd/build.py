@@ -3,6 +3,7 @@
   tfhe_amd/libtfhe_hip.so     HIP kernels + C-ABI (include/tfhe_hip.h), cross-compiled for gfx950
   tfhe_amd/libtfhe_client.so  client-side key generation / encryption (host C)
   oracle/liboracle.so         CPU restatement of the reference path (test infrastructure)
+  ..._80.so of each           the same sources built for the 80-bit parameter set (-DTFHE_HIP_LAMBDA=80)
   oracle/_ref/libtfhe_ref.so  the reference itself, only where /root/reference exists (authoring container)
 """
 import os
@@ -26,8 +27,15 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build_hip(force=False):
-    out = os.path.join(ROOT, "tfhe_amd", "libtfhe_hip.so")
+LAMBDAS = (128, 80)
+
+
+def _suffix(lam):
+    return "" if lam == 128 else "_%d" % lam
+
+
+def build_hip(force=False, lam=128):
+    out = os.path.join(ROOT, "tfhe_amd", "libtfhe_hip%s.so" % _suffix(lam))
     srcs = [os.path.join(CSRC, "tfhe_hip.hip"), os.path.join(CSRC, "br_core.h"),
             os.path.join(CSRC, "compat_libtfhe.cpp"), os.path.join(CSRC, "wire_io.cpp"),
             os.path.join(CSRC, "internal.h"), os.path.join(ROOT, "include", "tfhe_hip.h"),
@@ -35,7 +43,7 @@ def build_hip(force=False):
     srcs = [s for s in srcs if os.path.exists(s)]
     if force or _stale(out, srcs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-I" + os.path.join(ROOT, "include"), "-o", out, os.path.join(CSRC, "tfhe_hip.hip")]
+               "-DTFHE_HIP_LAMBDA=%d" % lam, "-I" + os.path.join(ROOT, "include"), "-o", out, os.path.join(CSRC, "tfhe_hip.hip")]
         for extra in ("compat_libtfhe.cpp", "wire_io.cpp"):
             if os.path.exists(os.path.join(CSRC, extra)):
                 cmd.append(os.path.join(CSRC, extra))
@@ -43,11 +51,11 @@ def build_hip(force=False):
     return out
 
 
-def build_client(force=False):
-    out = os.path.join(ROOT, "tfhe_amd", "libtfhe_client.so")
+def build_client(force=False, lam=128):
+    out = os.path.join(ROOT, "tfhe_amd", "libtfhe_client%s.so" % _suffix(lam))
     src = os.path.join(CSRC, "client_keys.c")
     if force or _stale(out, [src]):
-        _run(["gcc", "-std=gnu11", "-O2", "-fPIC", "-shared", "-o", out, src, "-lpthread"])
+        _run(["gcc", "-std=gnu11", "-O2", "-fPIC", "-shared", "-DTFHE_HIP_LAMBDA=%d" % lam, "-o", out, src, "-lpthread"])
     return out
 
 
@@ -72,8 +80,9 @@ def build_test_harness(force=False):
 
 
 def build_all(force=False):
-    build_hip(force)
-    build_client(force)
+    for lam in LAMBDAS:
+        build_hip(force, lam)
+        build_client(force, lam)
     build_oracle(force)
     build_test_harness(force)
 

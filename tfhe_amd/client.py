@@ -26,13 +26,15 @@ def _p(a):
 
 
 class Client:
-    def __init__(self):
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("%s not built: run `python -m tfhe_amd.build`" % LIB_PATH)
-        self.lib = ctypes.CDLL(LIB_PATH)
+    def __init__(self, params=PARAMS):
+        self.params = params
+        path = LIB_PATH if params.lam == 128 else os.path.join(_HERE, "libtfhe_client%s.so" % params.suffix)
+        if not os.path.exists(path):
+            raise RuntimeError("%s not built: run `python -m tfhe_amd.build`" % path)
+        self.lib = ctypes.CDLL(path)
 
     def keygen(self, seed=42):
-        P = PARAMS
+        P = self.params
         lk = np.zeros(P.n, np.int32)
         tk = np.zeros(P.N, np.int32)
         bk = np.zeros((P.n, P.kpl, 2, P.N), np.int32)
@@ -42,7 +44,7 @@ class Client:
 
     def encrypt(self, keys, bits, seed=1):
         bits = np.ascontiguousarray(bits, dtype=np.uint8).reshape(-1)
-        out = np.zeros((bits.shape[0], PARAMS.n + 1), np.int32)
+        out = np.zeros((bits.shape[0], self.params.n + 1), np.int32)
         self.lib.tfhe_client_encrypt(ctypes.c_uint64(seed), _p(keys.lwe_key), _p(bits), ctypes.c_int64(bits.shape[0]),
                                      _p(out))
         return out

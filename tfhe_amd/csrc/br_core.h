@@ -38,11 +38,33 @@ namespace brc {
 
 constexpr int kN = 1024;       // polynomial degree
 constexpr int kNh = 512;       // N/2
+// The parameter set is a compile-time choice: the library is built once per set (tfhe_amd/build.py), the default
+// 128-bit set of tfhe_gate_bootstrapping.cpp:51-75 as libtfhe_hip.so and, with -DTFHE_HIP_LAMBDA=80, the 80-bit set
+// of :23-48 as libtfhe_hip_80.so.  N, k and the keyswitch decomposition (t = 8, base 4) are the same in both.
+#ifndef TFHE_HIP_LAMBDA
+#define TFHE_HIP_LAMBDA 128
+#endif
+#if TFHE_HIP_LAMBDA == 128
 constexpr int kLwe = 630;      // n
 constexpr int kL = 3;          // decomposition length
-constexpr int kKpl = 6;        // (k+1)*l rows
 constexpr int kBgbit = 7;
-constexpr uint32_t kDecompOffset = 2164391936u;  // reference src/include/tfhe_core.h:24
+#elif TFHE_HIP_LAMBDA == 80
+constexpr int kLwe = 500;
+constexpr int kL = 2;
+constexpr int kBgbit = 10;
+#else
+#error "TFHE_HIP_LAMBDA must be 128 or 80"
+#endif
+constexpr int kKpl = 2 * kL;   // (k+1)*l rows
+// sum over the digits of Bg/2 at the digit's position (tgsw.cpp:21-27; 2164391936 = src/include/tfhe_core.h:24 for the
+// 128-bit set): one bit per digit, 31 - p*Bgbit.  The same word is the mask of the digits' top bits.
+constexpr uint32_t decomp_offset_bits() {
+    uint32_t m = 0;
+    for (int p = 0; p < kL; p++) m |= 1u << (31 - p * kBgbit);
+    return m;
+}
+constexpr uint32_t kDecompOffset = decomp_offset_bits();
+static_assert(TFHE_HIP_LAMBDA != 128 || kDecompOffset == 2164391936u, "offset of the default set");
 constexpr int kTwEntries = 2044;                 // base tables, sizes 8..2048: sum of size/2
 // Per-lane twiddle image kept in LDS: 31 slots x 64 lanes; slot s of lane l sits at [s*64 + l], so every table read of
 // the lane-dependent phases is `lane base + constant` (one address register, immediate offsets) and the 64 lanes of
@@ -435,12 +457,10 @@ BRC_HD int32_t rot_minus_one(const int32_t *acc, int a, int j) {
     return (int32_t) (rot - (uint32_t) acc[j]);
 }
 // gadget digit p (0..l-1) of a Torus32: reference tgsw-functions.cpp:297-315:
-//   u = t + offset;  digit_p = ((u >> (32 - 7(p+1))) & 127) - 64
-// field - 64 equals the field read as a signed 7-bit number after flipping its top bit, so the three digits of one
+//   u = t + offset;  digit_p = ((u >> (32 - Bgbit(p+1))) & (Bg-1)) - Bg/2
+// field - Bg/2 equals the field read as a signed Bgbit-bit number after flipping its top bit, so the digits of one
 // coefficient cost one add, one xor (decomp_prepare, once) and one signed bit-field extract each (decomp_digit).
-BRC_HD uint32_t decomp_prepare(int32_t t) {
-    return ((uint32_t) t + kDecompOffset) ^ ((1u << 31) | (1u << 24) | (1u << 17));
-}
+BRC_HD uint32_t decomp_prepare(int32_t t) { return ((uint32_t) t + kDecompOffset) ^ kDecompOffset; }
 BRC_HD int32_t decomp_digit(uint32_t prepared, int p) {
     return ((int32_t) (prepared << (kBgbit * p))) >> (32 - kBgbit);
 }

@@ -12,14 +12,31 @@
  * not reproducible across standard libraries), so that tests, smoke() and bench.py regenerate identical keys on
  * the GPU box from a seed instead of shipping 145 MB of key files.  Distributions: key bits and masks uniform;
  * noise = Irwin-Hall(12) approximation of a centred Gaussian with the reference's standard deviations
- * (2^-15 for LWE_n / keyswitch rows, 2^-25 for the bootstrapping key; tfhe_gate_bootstrapping.cpp:62-63).
+ * (2^-15 for LWE_n / keyswitch rows, 2^-25 for the bootstrapping key; tfhe_gate_bootstrapping.cpp:62-63; for the
+ * 80-bit set 2.44e-5 and 7.18e-9, :35-36).
  */
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
-enum { CN = 630, CBIGN = 1024, CL = 3, CKPL = 6, CBGBIT = 7, CT = 8, CBASEBIT = 2, CBASE = 4 };
+/* one library per parameter set, as for libtfhe_hip (include/tfhe_hip.h): -DTFHE_HIP_LAMBDA=80 selects the 80-bit set.
+ * Noise multipliers: standard deviation x 2^40, rounded (tfhe_gate_bootstrapping.cpp:35-36,62-63). */
+#ifndef TFHE_HIP_LAMBDA
+#define TFHE_HIP_LAMBDA 128
+#endif
+#if TFHE_HIP_LAMBDA == 128
+enum { CN = 630, CL = 3, CBGBIT = 7 };
+#define KS_NOISE_M ((int64_t) 1 << 25) /* 2^-15 */
+#define BK_NOISE_M ((int64_t) 1 << 15) /* 2^-25 */
+#elif TFHE_HIP_LAMBDA == 80
+enum { CN = 500, CL = 2, CBGBIT = 10 };
+#define KS_NOISE_M ((int64_t) 26828165) /* 2.44e-5 */
+#define BK_NOISE_M ((int64_t) 7894)     /* 7.18e-9 */
+#else
+#error "TFHE_HIP_LAMBDA must be 128 or 80"
+#endif
+enum { CBIGN = 1024, CKPL = 2 * CL, CT = 8, CBASEBIT = 2, CBASE = 4 };
 
 typedef struct { uint64_t s[4]; } rng_t;
 
@@ -40,16 +57,17 @@ static uint64_t rng_next(rng_t *r) { /* xoshiro256** */
     return res;
 }
 static inline int32_t rng_torus(rng_t *r) { return (int32_t) (uint32_t) (rng_next(r) >> 32); }
-/* centred noise with standard deviation 2^-log2inv (as a Torus32): the sum of 12 uniform 32-bit words has
+/* centred noise with standard deviation m / 2^40 (as a Torus32; m = 2^25 gives 2^-15 and rounds exactly as the
+ * shift by 15 it replaces): the sum of 12 uniform 32-bit words has
  * variance 2^64, i.e. standard deviation exactly 2^32 = "1.0" on the torus scale */
-static int32_t rng_gauss(rng_t *r, int log2inv) {
+static int32_t rng_gauss(rng_t *r, int64_t m) {
     int64_t s = 0;
     for (int i = 0; i < 6; i++) {
         uint64_t w = rng_next(r);
         s += (int64_t) (w >> 32) + (int64_t) (w & 0xffffffffu);
     }
     s -= (int64_t) 6 << 32;
-    return (int32_t) ((s + ((int64_t) 1 << (log2inv - 1))) >> log2inv);
+    return (int32_t) ((s * m + ((int64_t) 1 << 39)) >> 40); /* |s| < 2^35, m < 2^26 */
 }
 
 /* b += key * a  in Z[X]/(X^N+1), key binary (reference torusPolynomialAddMulR, used at tlwe-functions.cpp:35) */
@@ -74,7 +92,7 @@ static void *bk_worker(void *arg) {
         rng_seed(&r, j->seed, 0x10000 + (uint64_t) i);
         for (int p = 0; p < CKPL; p++) {
             int32_t *a = j->bk + (((size_t) i * CKPL + p) * 2 + 0) * CBIGN, *b = a + CBIGN;
-            for (int q = 0; q < CBIGN; q++) b[q] = rng_gauss(&r, 25);
+            for (int q = 0; q < CBIGN; q++) b[q] = rng_gauss(&r, BK_NOISE_M);
             for (int q = 0; q < CBIGN; q++) a[q] = rng_torus(&r);
             addmul_binkey(b, j->tlwe_key, a);
             /* + message * H: row p belongs to block p / l and adds s_i / Bg^(p%l+1) to that block's polynomial
@@ -103,7 +121,7 @@ void tfhe_client_keygen(uint64_t seed, int32_t *lwe_key /*n*/, int32_t *tlwe_key
                 int32_t *row = ks + (((size_t) i * CT + j) * CBASE + h) * (CN + 1);
                 if (h == 0) { memset(row, 0, sizeof(int32_t) * (CN + 1)); continue; }
                 uint32_t b = (uint32_t) (tlwe_key[i] * h) << (32 - (j + 1) * CBASEBIT);
-                b += (uint32_t) rng_gauss(&r, 15);
+                b += (uint32_t) rng_gauss(&r, KS_NOISE_M);
                 for (int q = 0; q < CN; q++) {
                     row[q] = rng_torus(&r);
                     b += (uint32_t) row[q] * (uint32_t) lwe_key[q];
@@ -131,7 +149,7 @@ void tfhe_client_encrypt(uint64_t seed, const int32_t *lwe_key, const uint8_t *b
         rng_seed(&r, seed, 0x100000000ULL + (uint64_t) c);
         int32_t *ct = out + c * (CN + 1);
         uint32_t b = bits[c] ? (1u << 29) : (0u - (1u << 29));
-        b += (uint32_t) rng_gauss(&r, 15);
+        b += (uint32_t) rng_gauss(&r, KS_NOISE_M);
         for (int q = 0; q < CN; q++) {
             ct[q] = rng_torus(&r);
             b += (uint32_t) ct[q] * (uint32_t) lwe_key[q];

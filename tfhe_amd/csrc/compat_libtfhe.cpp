@@ -81,9 +81,9 @@ extern "C" {
 int tfhe_hip_load_cloud_keyset(tfhe_hip_ctx *ctx, const TFheGateBootstrappingCloudKeySet *keyset) {
     if (!ctx || !keyset || !keyset->bkFFT || !keyset->bkFFT->bkFFT || !keyset->bkFFT->ks) return TFHE_HIP_ERR_ARG;
     const LweBootstrappingKeyFFT *k = keyset->bkFFT;
-    if (k->in_out_params->n != kn || k->accum_params->N != kN || k->accum_params->k != 1 || k->bk_params->l != 3 ||
-        k->bk_params->Bgbit != 7)
-        return TFHE_HIP_ERR_ARG;   // only the default parameter set (reference tfhe_core.h:13-24 is constexpr too)
+    if (k->in_out_params->n != kn || k->accum_params->N != kN || k->accum_params->k != 1 || k->bk_params->l != TFHE_HIP_L ||
+        k->bk_params->Bgbit != TFHE_HIP_BGBIT)
+        return TFHE_HIP_ERR_ARG;   // only the parameter set this library was built for (include/tfhe_hip.h)
     return load_keys(ctx, k->bkFFT, k->ks);
 }
 

@@ -32,7 +32,7 @@ namespace {
 
 constexpr int kExt = kN + 1;      // extracted LWE_N sample length
 constexpr int kCt = kLwe + 1;     // LWE_n sample length
-constexpr int kKsRow = 632;       // keyswitch row padded to a multiple of 4 dwords
+constexpr int kKsRow = (kCt + 3) / 4 * 4;  // keyswitch row padded to a multiple of 4 dwords (632)
 constexpr int kKsT = 8, kKsBasebit = 2;
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -522,7 +522,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
 //      | the 630 rotation amounts (computed once, so that no global load sits on the per-iteration critical path)
 //      | prepared differences 8 KB (see prepare_diff)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kCoopWaves = 6;
+constexpr int kCoopWaves = kKpl;
+constexpr int kShapeCoop = 6;  // the name of this launch shape in launch_br / TFHE_HIP_BR_WAVES (whatever kKpl is)
 constexpr int kCoopLds = kTwLaneEntries * (int) sizeof(c64) + 2 * kN * 4 + kCoopWaves * 2 * kNh * (int) sizeof(c64) + 640 * 4 +
                          2 * kN * 4;
 
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(192) void k_keyswitch(const int32_t *__restrict__ i
     for (int g = 0; g < kKsG; g++) {
         const long long gi = (g0 + g < B) ? g0 + g : B - 1;
         acc[g] = u32x4{0u, 0u, 0u, 0u};
-        if (t == kKsThreads - 1) acc[g].z = (uint32_t) in[gi * kExt + kN];  // coefficient 630 = b
+        if (t == kLwe / 4) acc[g][kLwe % 4] = (uint32_t) in[gi * kExt + kN];  // coefficient n = b
     }
     const uint32_t prec_offset = 1u << (32 - (1 + kKsBasebit * kKsT));
     const u32x4 *rows = reinterpret_cast<const u32x4 *>(ks) + t;
@@ -755,7 +756,8 @@ __global__ __launch_bounds__(192) void k_keyswitch(const int32_t *__restrict__ i
 // (8 digits j x 4 digit values d).  A fragments are built in registers from the transposed input; B fragments are
 // 16-byte loads from the key stored as int8[i][limb][q][j][d].
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kKsQ = 640;     // output coefficients padded to 20 tiles of 32
+constexpr int kKsQ = (kCt + 127) / 128 * 128;  // output coefficients padded to whole workgroups of 4 x 32 (640)
+constexpr int kKsYB = kKsQ / 128;            // workgroups over the coefficients (5)
 constexpr int kKsMT = 2;      // 32-ciphertext tiles per wave
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
@@ -1125,6 +1127,11 @@ __global__ __launch_bounds__(256) void k_combine2048(const int32_t *__restrict__
 // kernels reproduce, bit for bit, the portable generator of tfhe_amd/csrc/client_keys.c (one xoshiro256** stream per
 // sample, Irwin-Hall(12) noise of standard deviation 2^-15), so a ciphertext is a function of (seed, index, bit, key).
 // ---------------------------------------------------------------------------------------------------------------
+#if TFHE_HIP_LAMBDA == 128
+constexpr int64_t kKsNoiseM = (int64_t) 1 << 25, kBkNoiseM = (int64_t) 1 << 15;  // 2^-15, 2^-25 (x 2^40)
+#else
+constexpr int64_t kKsNoiseM = 26828165, kBkNoiseM = 7894;  // 2.44e-5, 7.18e-9 (tfhe_gate_bootstrapping.cpp:35-36)
+#endif
 struct ClientRng {
     uint64_t s[4];
 };
@@ -1144,14 +1151,15 @@ __device__ __forceinline__ uint64_t crng_next(ClientRng &r) {  // xoshiro256**
     r.s[2] ^= r.s[0]; r.s[3] ^= r.s[1]; r.s[1] ^= r.s[2]; r.s[0] ^= r.s[3]; r.s[2] ^= t; r.s[3] = crng_rotl(r.s[3], 45);
     return res;
 }
-__device__ __forceinline__ int32_t crng_gauss(ClientRng &r, int log2inv) {
+__device__ __forceinline__ int32_t crng_gauss(ClientRng &r, int64_t m) {  // standard deviation m / 2^40
+
     int64_t s = 0;
     for (int i = 0; i < 6; i++) {
         const uint64_t w = crng_next(r);
         s += (int64_t) (w >> 32) + (int64_t) (w & 0xffffffffu);
     }
     s -= (int64_t) 6 << 32;
-    return (int32_t) ((s + ((int64_t) 1 << (log2inv - 1))) >> log2inv);
+    return (int32_t) ((s * m + ((int64_t) 1 << 39)) >> 40);
 }
 // one thread per sample (the generator of a sample is sequential); the 630 mask words of 64 samples pass through LDS
 // so that the global stores are coalesced rows
@@ -1164,7 +1172,7 @@ __global__ __launch_bounds__(64) void k_client_encrypt(uint64_t seed, const int3
     crng_seed(r, seed, 0x100000000ULL + (uint64_t) (first + c));
     const bool live = c < count;
     uint32_t b = live && bits[c] ? (1u << 29) : (0u - (1u << 29));
-    b += (uint32_t) crng_gauss(r, 15);
+    b += (uint32_t) crng_gauss(r, kKsNoiseM);
     for (int q0 = 0; q0 < kLwe; q0 += 64) {
         const int nq = kLwe - q0 < 64 ? kLwe - q0 : 64;
         for (int q = 0; q < nq; q++) {
@@ -1203,7 +1211,7 @@ __global__ __launch_bounds__(64) void k_client_bk_draw(uint64_t seed, int32_t *_
     crng_seed(r, seed, 0x10000ULL + (uint64_t) i);
     for (int p = 0; p < kKpl; p++) {
         int32_t *a = bk_coef + (((size_t) i * kKpl + p) * 2 + 0) * kN, *b = a + kN;
-        for (int q = 0; q < kN; q++) b[q] = crng_gauss(r, 25);
+        for (int q = 0; q < kN; q++) b[q] = crng_gauss(r, kBkNoiseM);
         for (int q = 0; q < kN; q++) a[q] = (int32_t) (uint32_t) (crng_next(r) >> 32);
     }
 }
@@ -1375,8 +1383,8 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
     int waves = c->br_waves;
     // (measured: 512 gates 7.7 ms as two rounds of the latency kernel against 9.6 ms with 4 waves per workgroup;
     //  640 gates 11.4 ms against 9.6 ms)
-    if (waves == 0) waves = A.B <= 512 ? (MODE == MODE_EXTMUL ? (A.B <= 256 ? 1 : 4) : kCoopWaves) : A.B <= 1024 ? 4 : 8;
-    if (waves == kCoopWaves && MODE != MODE_EXTMUL) {  // one workgroup per ciphertext (latency shape)
+    if (waves == 0) waves = A.B <= 512 ? (MODE == MODE_EXTMUL ? (A.B <= 256 ? 1 : 4) : kShapeCoop) : A.B <= 1024 ? 4 : 8;
+    if (waves == kShapeCoop && MODE != MODE_EXTMUL) {  // one workgroup per ciphertext (latency shape)
         HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate_coop<MODE == MODE_EXTMUL ? MODE_RAW : MODE>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kCoopLds));
         hipLaunchKernelGGL((k_blind_rotate_coop<MODE == MODE_EXTMUL ? MODE_RAW : MODE>), dim3((unsigned) A.B),
@@ -1384,7 +1392,7 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
         HIPCHK(hipGetLastError());
         return TFHE_HIP_OK;
     }
-    if (waves == kCoopWaves) waves = 1;
+    if (waves == kShapeCoop) waves = 1;
     const size_t lds = kTwLaneEntries * sizeof(c64) + (size_t) waves * kBrLdsPerWave;
     const unsigned grid = (unsigned) ((A.B + waves - 1) / waves);
     auto go = [&](auto kernel) -> int {
@@ -1410,14 +1418,14 @@ int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B,
                            (uint32_t *) c->abart.p, d_in, B, Bp, kj);
         const long long xblocks = Bp / (32 * kKsMT);
         int S = 1;
-        while (S < 16 && 5 * xblocks * S < 256) S *= 2;   // fill the 256 CUs
+        while (S < 16 && kKsYB * xblocks * S < 256) S *= 2;   // fill the 256 CUs
         if (S == 1) {
-            hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) xblocks, 5), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) xblocks, kKsYB), dim3(256), 0, c->stream,
                                (const uint32_t *) c->abart.p, (const int8_t *) c->kl, d_in, d_out, B, Bp, kj,
                                (uint32_t *) nullptr);
         } else {
             HIPCHK(c->ks_part.reserve((size_t) S * Bp * kCt * sizeof(uint32_t)));
-            hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) xblocks, 5, (unsigned) S), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) xblocks, kKsYB, (unsigned) S), dim3(256), 0, c->stream,
                                (const uint32_t *) c->abart.p, (const int8_t *) c->kl, d_in, d_out, B, Bp, kj,
                                (uint32_t *) c->ks_part.p);
             hipLaunchKernelGGL(k_ks_reduce, dim3((unsigned) ((B * kCt + 255) / 256)), dim3(256), 0, c->stream,
@@ -1479,6 +1487,10 @@ int tfhe_hip_internal_fail(int code, const char *msg) { return fail(code, msg ? 
 extern "C" {
 
 const char *tfhe_hip_last_error(void) { return g_err.c_str(); }
+void tfhe_hip_param_set(int32_t out[8]) {
+    const int32_t v[8] = {TFHE_HIP_LAMBDA, kLwe, kN, 1, kL, kBgbit, kKsT, kKsBasebit};
+    for (int i = 0; i < 8; i++) out[i] = v[i];
+}
 
 int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     if (!out) return fail(TFHE_HIP_ERR_ARG, "null out pointer");
@@ -1494,7 +1506,7 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     c->device = device;
     c->ka = make_phaseA_consts([&](int i) { return tw[i]; });
     const char *w = getenv("TFHE_HIP_BR_WAVES");
-    if (w && (atoi(w) == 8 || atoi(w) == 4 || atoi(w) == 1 || atoi(w) == kCoopWaves)) c->br_waves = atoi(w);
+    if (w && (atoi(w) == 8 || atoi(w) == 4 || atoi(w) == 1 || atoi(w) == kShapeCoop)) c->br_waves = atoi(w);
     const char *km = getenv("TFHE_HIP_KS_MFMA");
     if (km) c->ks_mfma = atoi(km) != 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -82,7 +82,7 @@ int expect_section(Cursor &c, const char *title, std::initializer_list<std::pair
         if (endp == it->second.c_str()) return bad(std::string(title) + ": property " + kv.first + " is not a number");
         if (v != kv.second)
             return bad(std::string(title) + ": " + kv.first + " = " + std::to_string(v) + ", this build supports only " +
-                       std::to_string(kv.second) + " (default 128-bit parameter set)");
+                       std::to_string(kv.second) + " (this library is built for the " + std::to_string(TFHE_HIP_LAMBDA) + "-bit parameter set)");
     }
     return TFHE_HIP_OK;
 }
@@ -91,7 +91,7 @@ int read_params(Cursor &c) {  // read_new_tfheGateBootstrappingParameters, tfhe_
     if (int r = expect_section(c, "GATEBOOTSPARAMS", {{"ks_t", kT}, {"ks_basebit", 2}})) return r;
     if (int r = expect_section(c, "LWEPARAMS", {{"n", kLwe}})) return r;
     if (int r = expect_section(c, "TLWEPARAMS", {{"N", kN}, {"k", 1}})) return r;
-    return expect_section(c, "TGSWPARAMS", {{"l", 3}, {"Bgbit", 7}});
+    return expect_section(c, "TGSWPARAMS", {{"l", TFHE_HIP_L}, {"Bgbit", TFHE_HIP_BGBIT}});
 }
 
 int read_blob(Cursor &c, int32_t uid, const char *what, double *variance, int32_t *dst, size_t elems) {
@@ -135,14 +135,17 @@ void write_section(Sink &s, const char *title, const std::map<std::string, std::
     for (const auto &kv : props) s.text(kv.first + ": " + kv.second + "\n");
     s.text(std::string("-----END ") + title + "-----\n");
 }
-// default_128bit_gate_bootstrapping_parameters, tfhe_gate_bootstrapping.cpp:51-75
+#if TFHE_HIP_LAMBDA == 128  // default_128bit_gate_bootstrapping_parameters, tfhe_gate_bootstrapping.cpp:51-75
 const double kKsStdev = 1.0 / 32768.0, kBkStdev = 1.0 / 33554432.0, kMaxStdev = 0.012467;
+#else                       // default_80bit_gate_bootstrapping_parameters, :23-48
+const double kKsStdev = 2.44e-5, kBkStdev = 7.18e-9, kMaxStdev = 0.012467;
+#endif
 void write_params(Sink &s) {  // write_tfheGateBootstrappingParameters, tfhe_io.cpp:1031-1035
     write_section(s, "GATEBOOTSPARAMS", {{"ks_t", fmt_int(kT)}, {"ks_basebit", fmt_int(2)}});
     write_section(s, "LWEPARAMS", {{"n", fmt_int(kLwe)}, {"alpha_min", fmt_dbl(kKsStdev)}, {"alpha_max", fmt_dbl(kMaxStdev)}});
     write_section(s, "TLWEPARAMS", {{"N", fmt_int(kN)}, {"k", fmt_int(1)}, {"alpha_min", fmt_dbl(kBkStdev)},
                                     {"alpha_max", fmt_dbl(kMaxStdev)}});
-    write_section(s, "TGSWPARAMS", {{"l", fmt_int(3)}, {"Bgbit", fmt_int(7)}});
+    write_section(s, "TGSWPARAMS", {{"l", fmt_int(TFHE_HIP_L)}, {"Bgbit", fmt_int(TFHE_HIP_BGBIT)}});
 }
 
 struct File {

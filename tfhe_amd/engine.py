@@ -10,17 +10,23 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(_HERE, "libtfhe_hip.so")  # override: A/B builds
 
 
-class PARAMS:
-    n = 630
-    N = 1024
-    k = 1
-    l = 3
-    Bgbit = 7
-    kpl = 6
-    ks_t = 8
-    ks_basebit = 2
-    ks_base = 4
-    MU = 1 << 29
+class ParamSet:
+    """a gate-bootstrapping parameter set (tfhe_gate_bootstrapping.cpp:23-75); one native library per set"""
+
+    def __init__(self, lam, n, l, Bgbit, ks_stdev, bk_stdev):
+        self.lam, self.n, self.l, self.Bgbit = lam, n, l, Bgbit
+        self.N, self.k, self.kpl = 1024, 1, 2 * l
+        self.ks_t, self.ks_basebit, self.ks_base = 8, 2, 4
+        self.ks_stdev, self.bk_stdev = ks_stdev, bk_stdev
+        self.MU = 1 << 29
+        self.suffix = "" if lam == 128 else "_%d" % lam     # libtfhe_hip.so / libtfhe_hip_80.so
+
+    def __repr__(self):
+        return "ParamSet(lambda=%d, n=%d, l=%d, Bgbit=%d)" % (self.lam, self.n, self.l, self.Bgbit)
+
+
+PARAMS = ParamSet(128, 630, 3, 7, 2.0 ** -15, 2.0 ** -25)    # the default set; every function defaults to it
+PARAMS_80 = ParamSet(80, 500, 2, 10, 2.44e-5, 7.18e-9)
 
 
 class Gate(enum.IntEnum):
@@ -45,7 +51,7 @@ class TfheHipError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 EXPORTS = [
     "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_load_keys_coef", "tfhe_hip_load_keys_fft",
@@ -57,19 +63,32 @@ EXPORTS = [
     "tfhe_hip_dev_alloc", "tfhe_hip_dev_free", "tfhe_hip_copy_to_dev", "tfhe_hip_copy_from_dev",
     "tfhe_hip_negacyclic_mul2048_batch", "tfhe_hip_negacyclic_mul2048_batch_dev",
     "tfhe_hip_encrypt_batch", "tfhe_hip_encrypt_batch_dev", "tfhe_hip_phase_batch", "tfhe_hip_keygen_bk",
+    "tfhe_hip_param_set",
 ]
 
 
-def load_library():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise TfheHipError("%s not built: run `python -m tfhe_amd.build`" % LIB_PATH)
-        lib = ctypes.CDLL(LIB_PATH)
+def lib_path(params=PARAMS):
+    if params.lam == 128:
+        return LIB_PATH
+    return os.path.join(_HERE, "libtfhe_hip%s.so" % params.suffix)
+
+
+def load_library(params=PARAMS):
+    if params.lam not in _libs:
+        path = lib_path(params)
+        if not os.path.exists(path):
+            raise TfheHipError("%s not built: run `python -m tfhe_amd.build`" % path)
+        lib = ctypes.CDLL(path)
         lib.tfhe_hip_last_error.restype = ctypes.c_char_p
         lib.tfhe_hip_stream.restype = ctypes.c_void_p
-        _lib = lib
-    return _lib
+        lib.tfhe_hip_param_set.restype = None
+        got = (ctypes.c_int32 * 8)()
+        lib.tfhe_hip_param_set(got)
+        want = [params.lam, params.n, params.N, params.k, params.l, params.Bgbit, params.ks_t, params.ks_basebit]
+        if list(got) != want:
+            raise TfheHipError("%s is built for %r, expected %r" % (path, list(got), want))
+        _libs[params.lam] = lib
+    return _libs[params.lam]
 
 
 def _p(arr):
@@ -88,8 +107,9 @@ def _i32(arr, shape_tail):
 class Engine:
     """One engine = one tfhe_hip_ctx = one GPU."""
 
-    def __init__(self, device=0):
-        self.lib = load_library()
+    def __init__(self, device=0, params=PARAMS):
+        self.params = params
+        self.lib = load_library(params)
         ctx = ctypes.c_void_p()
         rc = self.lib.tfhe_hip_create(ctypes.byref(ctx), int(device))
         if rc != 0:
@@ -114,27 +134,27 @@ class Engine:
 
     # ---- keys ----
     def load_keys_coef(self, bk_coef, ks):
-        P = PARAMS
+        P = self.params
         bk = _i32(bk_coef, (P.n, P.kpl, 2, P.N))
         k = _i32(ks, (P.N, P.ks_t, P.ks_base, P.n + 1))
         self._chk(self.lib.tfhe_hip_load_keys_coef(self.ctx, _p(bk), _p(k)), "load_keys_coef")
 
     def load_keys_fft(self, bkfft, ks):
-        P = PARAMS
+        P = self.params
         bk = np.ascontiguousarray(bkfft, dtype=np.float64)
         assert bk.size == P.n * P.kpl * 2 * P.N
         k = _i32(ks, (P.N, P.ks_t, P.ks_base, P.n + 1))
         self._chk(self.lib.tfhe_hip_load_keys_fft(self.ctx, _p(bk), _p(k)), "load_keys_fft")
 
     def get_bkfft(self):
-        P = PARAMS
+        P = self.params
         out = np.empty((P.n, P.kpl, 2, P.N // 2, 2), dtype=np.float64)
         self._chk(self.lib.tfhe_hip_get_bkfft(self.ctx, _p(out)), "get_bkfft")
         return out
 
     # ---- gates, host buffers ----
     def gate_batch(self, gate, a=None, b=None, c=None, count=None):
-        P = PARAMS
+        P = self.params
         a, b, c = (_i32(x, (P.n + 1,)) for x in (a, b, c))
         if count is None:
             count = a.shape[0]
@@ -144,7 +164,7 @@ class Engine:
         return out
 
     def bootstrap_batch(self, x, mu=PARAMS.MU, with_ks=True):
-        P = PARAMS
+        P = self.params
         x = _i32(x, (P.n + 1,))
         out = np.empty((x.shape[0], (P.n if with_ks else P.N) + 1), dtype=np.int32)
         self._chk(self.lib.tfhe_hip_bootstrap_batch(self.ctx, _p(out), _p(x), ctypes.c_int32(mu),
@@ -152,7 +172,7 @@ class Engine:
         return out
 
     def keyswitch_batch(self, u):
-        P = PARAMS
+        P = self.params
         u = _i32(u, (P.N + 1,))
         out = np.empty((u.shape[0], P.n + 1), dtype=np.int32)
         self._chk(self.lib.tfhe_hip_keyswitch_batch(self.ctx, _p(out), _p(u), ctypes.c_int64(u.shape[0])),
@@ -225,15 +245,15 @@ class Engine:
 
     # ---- client-side bulk operations ----
     def encrypt_batch(self, seed, lwe_key, bits, first_index=0):
-        key = _i32(lwe_key, (PARAMS.n,)).reshape(-1)
+        key = _i32(lwe_key, (self.params.n,)).reshape(-1)
         b = np.ascontiguousarray(bits, dtype=np.uint8).reshape(-1)
-        out = np.empty((b.shape[0], PARAMS.n + 1), dtype=np.int32)
+        out = np.empty((b.shape[0], self.params.n + 1), dtype=np.int32)
         self._chk(self.lib.tfhe_hip_encrypt_batch(self.ctx, _p(out), ctypes.c_uint64(seed), ctypes.c_int64(first_index),
                                                   _p(key), _p(b), ctypes.c_int64(b.shape[0])), "encrypt_batch")
         return out
 
     def encrypt_batch_dev(self, out, seed, lwe_key, bits, first_index=0):
-        key = _i32(lwe_key, (PARAMS.n,)).reshape(-1)
+        key = _i32(lwe_key, (self.params.n,)).reshape(-1)
         b = np.ascontiguousarray(bits, dtype=np.uint8).reshape(-1)
         self._chk(self.lib.tfhe_hip_encrypt_batch_dev(self.ctx, self._dptr(out), ctypes.c_uint64(seed),
                                                       ctypes.c_int64(first_index), _p(key), _p(b),
@@ -241,17 +261,17 @@ class Engine:
 
     def keygen_bk(self, seed, lwe_key, tlwe_key, ks, want_coef=False):
         """draw, transform and install the bootstrapping key on the device; returns its coefficient form if asked"""
-        lk = _i32(lwe_key, (PARAMS.n,)).reshape(-1)
-        tk = _i32(tlwe_key, (PARAMS.N,)).reshape(-1)
+        lk = _i32(lwe_key, (self.params.n,)).reshape(-1)
+        tk = _i32(tlwe_key, (self.params.N,)).reshape(-1)
         ks = np.ascontiguousarray(ks, dtype=np.int32)
-        out = np.empty((PARAMS.n, 6, 2, PARAMS.N), np.int32) if want_coef else None
+        out = np.empty((self.params.n, self.params.kpl, 2, self.params.N), np.int32) if want_coef else None
         self._chk(self.lib.tfhe_hip_keygen_bk(self.ctx, ctypes.c_uint64(seed), _p(lk), _p(tk), _p(ks),
                                               _p(out) if want_coef else None), "keygen_bk")
         return out
 
     def phase_batch(self, lwe_key, samples):
-        key = _i32(lwe_key, (PARAMS.n,)).reshape(-1)
-        s = _i32(samples, (PARAMS.n + 1,))
+        key = _i32(lwe_key, (self.params.n,)).reshape(-1)
+        s = _i32(samples, (self.params.n + 1,))
         out = np.empty(s.shape[0], dtype=np.int32)
         self._chk(self.lib.tfhe_hip_phase_batch(self.ctx, _p(out), _p(key), _p(s), ctypes.c_int64(s.shape[0])),
                   "phase_batch")
@@ -259,7 +279,7 @@ class Engine:
 
     # ---- stages ----
     def blind_rotate_batch(self, acc, bara):
-        P = PARAMS
+        P = self.params
         acc = _i32(acc, (2, P.N)).copy()
         bara = _i32(bara, (P.n,))
         self._chk(self.lib.tfhe_hip_blind_rotate_batch(self.ctx, _p(acc), _p(bara), ctypes.c_int64(acc.shape[0])),
@@ -267,7 +287,7 @@ class Engine:
         return acc
 
     def extern_mul_batch(self, acc, key_index):
-        P = PARAMS
+        P = self.params
         acc = _i32(acc, (2, P.N)).copy()
         idx = np.ascontiguousarray(key_index, dtype=np.int32).reshape(-1)
         assert idx.shape[0] == acc.shape[0]
@@ -282,14 +302,14 @@ class Engine:
         return self._fwd(polys, self.lib.tfhe_hip_torus_ifft_batch, "torus_ifft_batch")
 
     def _fwd(self, polys, fn, what):
-        P = PARAMS
+        P = self.params
         polys = _i32(polys, (P.N,))
         out = np.empty((polys.shape[0], P.N // 2, 2), dtype=np.float64)
         self._chk(fn(self.ctx, _p(out), _p(polys), ctypes.c_int64(polys.shape[0])), what)
         return out
 
     def torus_fft(self, spectra):
-        P = PARAMS
+        P = self.params
         s = np.ascontiguousarray(spectra, dtype=np.float64).reshape(-1, P.N // 2, 2)
         out = np.empty((s.shape[0], P.N), dtype=np.int32)
         self._chk(self.lib.tfhe_hip_torus_fft_batch(self.ctx, _p(out), _p(s), ctypes.c_int64(s.shape[0])),
@@ -297,7 +317,7 @@ class Engine:
         return out
 
     def negacyclic_mul2048(self, ipolys, tpolys):
-        a, b = _i32(ipolys, (2 * PARAMS.N,)), _i32(tpolys, (2 * PARAMS.N,))
+        a, b = _i32(ipolys, (2 * self.params.N,)), _i32(tpolys, (2 * self.params.N,))
         assert a.shape == b.shape
         out = np.empty_like(a)
         self._chk(self.lib.tfhe_hip_negacyclic_mul2048_batch(self.ctx, _p(out), _p(a), _p(b),
@@ -310,7 +330,7 @@ class Engine:
                   "negacyclic_mul2048_batch_dev")
 
     def negacyclic_mul(self, ipolys, tpolys):
-        P = PARAMS
+        P = self.params
         a, b = _i32(ipolys, (P.N,)), _i32(tpolys, (P.N,))
         assert a.shape == b.shape
         out = np.empty_like(a)

@@ -25,8 +25,9 @@ def _dist():
     return dist
 
 
-def broadcast_keys(keys, device=None, src=0):
+def broadcast_keys(keys, device=None, src=0, params=None):
     """rank `src` passes its KeySet, the others pass None; returns the KeySet on every rank"""
+    P = params if params is not None else globals()["P"]
     import torch
     dist = _dist()
     if not dist.is_initialized() or dist.get_world_size() == 1:
