@@ -1595,8 +1595,13 @@ int tfhe_hip_keygen_bk(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key, c
     HIPCHK(hipGetLastError());
     if (bk_coef_out) HIPCHK(hipMemcpyAsync(bk_coef_out, c->misc.p, coef_bytes, hipMemcpyDeviceToHost, c->stream));
     const int r = keys_from_coef_in_misc(c, ks);
-    hipMemsetAsync(c->abart.p, 0, (kLwe + kN) * sizeof(int32_t), c->stream);  // the secret keys do not stay on the device
-    hipStreamSynchronize(c->stream);
+    // the secret keys do not stay on the device, whatever the outcome above
+    const hipError_t w1 = hipMemsetAsync(c->abart.p, 0, (kLwe + kN) * sizeof(int32_t), c->stream);
+    const hipError_t w2 = hipStreamSynchronize(c->stream);
+    if (r == TFHE_HIP_OK && (w1 != hipSuccess || w2 != hipSuccess)) {
+        c->have_keys = false;
+        return fail(TFHE_HIP_ERR_HIP, "could not wipe the secret keys from device memory");
+    }
     return r;
 }
 
