@@ -13,6 +13,8 @@ using namespace brc;
 
 static std::vector<c64> g_tw(kTwEntries);
 static std::vector<c64> g_lane_tw(kTwLaneEntries);
+static std::vector<c64> g_half_tw(2 * kTwHalfSlots * 64);
+struct TWH { int h, lane; c64 operator()(int slot) const { return g_half_tw[(h * kTwHalfSlots + slot) * 64 + lane]; } };
 struct TW { c64 operator()(int i) const { return g_tw[i]; } };        // base tables
 struct TWL { int lane; c64 operator()(int slot) const { return g_lane_tw[slot * 64 + lane]; } };  // per-lane image
 static void init_tw() {
@@ -28,6 +30,7 @@ static void init_tw() {
         off += size;
     }
     build_lane_twiddles(g_lane_tw.data(), TW{});
+    build_half_twiddles(g_half_tw.data(), TW{});
 }
 
 static void emu_forward(const double *p, c64 *logical_out) {
@@ -63,6 +66,35 @@ static void emu_inverse(const c64 *C /*logical*/, int32_t *out, bool bounded) {
     for (int l = 0; l < 64; l++) { int32_t o[16]; if (bounded) inv_final<true>(o, v[l], TWL{l}); else inv_final<false>(o, v[l], TWL{l}); for (int r = 0; r < 16; r++) out[inv_yC(l, r)] = o[r]; }
 }
 
+// the inverse transform split over two waves (latency kernel): wave h produces the coefficients with y0 = h
+static void emu_inverse_split(const c64 *C /*logical*/, int32_t *out, bool bounded) {
+    TW tw;
+    const PhaseAConsts kc = make_phaseA_consts(tw);
+    for (int h = 0; h < 2; h++) {
+        static c64 v[64][8], scratch[512];
+        for (int l = 0; l < 64; l++) {
+            c64 E[8], O[8];
+            for (int r = 0; r < 8; r++) {
+                const int m0 = (br3(r) << 6) | l;
+                E[r] = C[m0];
+                O[r] = {C[511 - m0].re, -C[511 - m0].im};
+            }
+            if (h == 0) half_phaseA<0>(v[l], E, O, kc); else half_phaseA<1>(v[l], E, O, kc);
+        }
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) scratch[swz(fwd_xA(l, r))] = v[l][r];
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) v[l][r] = scratch[swz(fwd_xB(l, r))];
+        for (int l = 0; l < 64; l++) half_phaseBC<TWH_B>(v[l], TWH{h, l});
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) scratch[swz(fwd_xB(l, r))] = v[l][r];
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 8; r++) v[l][r] = scratch[swz(fwd_xC(l, r))];
+        for (int l = 0; l < 64; l++) half_phaseBC<TWH_C>(v[l], TWH{h, l});
+        for (int l = 0; l < 64; l++) {
+            int32_t o[8];
+            if (bounded) half_final<true>(o, v[l], TWH{h, l}); else half_final<false>(o, v[l], TWH{h, l});
+            for (int r = 0; r < 8; r++) out[half_y(l, r, h)] = o[r];
+        }
+    }
+}
+
 int main() {
     init_tw();
     std::mt19937_64 rng(123);
@@ -93,12 +125,18 @@ int main() {
         emu_inverse(C, r2, false);
         { int nd = 0; for (int i = 0; i < 1024; i++) if (r1[i] != r2[i]) nd++;
           if (nd) { bad++; if (bad < 8) printf("inverse trial %d: %d coefficients differ\n", trial, nd); } }
+        emu_inverse_split(C, r2, false);
+        { int nd = 0; for (int i = 0; i < 1024; i++) if (r1[i] != r2[i]) nd++;
+          if (nd) { bad++; if (bad < 8) printf("split inverse trial %d: %d coefficients differ\n", trial, nd); } }
         // bounded-range truncation (valid below 2^51): spectrum scaled so that the output stays below 2^50
         for (int i = 0; i < 512; i++) { C[i] = {got[i].re * 2000.0, got[i].im * 2000.0}; Cd[2*i] = C[i].re; Cd[2*i+1] = C[i].im; }
         oracle_TorusPolynomial_fft(r1, Cd);
         emu_inverse(C, r2, true);
         { int nd = 0; for (int i = 0; i < 1024; i++) if (r1[i] != r2[i]) nd++;
           if (nd) { bad++; if (bad < 8) printf("inverse(bounded) trial %d: %d coefficients differ\n", trial, nd); } }
+        emu_inverse_split(C, r2, true);
+        { int nd = 0; for (int i = 0; i < 1024; i++) if (r1[i] != r2[i]) nd++;
+          if (nd) { bad++; if (bad < 8) printf("split inverse(bounded) trial %d: %d coefficients differ\n", trial, nd); } }
     }
     {   // gadget decomposition: prepared-word form == reference form (tgsw-functions.cpp:297-315)
         int32_t t[1024], want[3 * 1024];

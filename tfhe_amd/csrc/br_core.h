@@ -419,6 +419,97 @@ BRC_HD void inv_phaseC(c64 (&v)[16], const TW &tw) {
     inv_level9(v, tw);
 }
 
+// =================================================================================================================
+// INVERSE TRANSFORM SPLIT OVER TWO WAVES (latency kernel): wave h = 0, 1 produces the coefficients y with y0 = h.
+//   Level 0 of the transform above pairs W[2y'] = c~[m0] and W[2y'+1] = c~[m0 + 512] = conj(C[511 - m0]), m0 = br9(y'):
+//   wave 0 forms the sums, wave 1 the differences, both straight from the spectrum - no exchange between the waves, no
+//   butterfly computed twice.  Levels 1..9 then stay inside {y : y0 = h}: on y' = y >> 1 (9 bits) they are levels
+//   k' = 0..8 with twiddle table(2^(k'+2), 2 j' + h), j' = y' mod 2^k'.  Layouts of y' = the forward transform's
+//   (fwd_xA / fwd_xB / fwd_xC, 8 values per lane), so the two transposes are the forward ones.
+//   Output of lane l, reg r: coefficient y = 2 (r<<6 | l) + h = r<<7 | l<<1 | h.
+//   Per-lane twiddle image: 12 slots per h (half_slot_index); quarter-turn partners folded as above.
+// =================================================================================================================
+constexpr int kTwHalfSlots = 12;
+enum { TWH_B = 0, TWH_C = 4, TWH_FIN = 8 };
+BRC_HD int half_slot_index(int h, int slot, int lane) {
+    const int l3 = lane & 7;
+    if (slot == 0) return tw_idx(32, 2 * l3 + h);                                  // k' = 3
+    if (slot == 1) return tw_idx(64, 2 * l3 + h);                                  // k' = 4, y'3 = 0
+    if (slot < 4) return tw_idx(128, 2 * (((slot - 2) << 3) | l3) + h);            // k' = 5, y'4 = 0, y'3 = slot-2
+    if (slot == 4) return tw_idx(256, 2 * lane + h);                               // k' = 6
+    if (slot == 5) return tw_idx(512, 2 * lane + h);                               // k' = 7, y'6 = 0
+    if (slot < 8) return tw_idx(1024, 2 * (((slot - 6) << 6) | lane) + h);         // k' = 8, y'7 = 0, y'6 = slot-6
+    return tw_idx(2048, ((slot - 8) << 7) | (lane << 1) | h);                      // last merge, r = slot-8 < 4
+}
+template <class BASE>
+inline void build_half_twiddles(c64 *out /*[2][kTwHalfSlots][64]*/, const BASE &base) {
+    for (int h = 0; h < 2; h++)
+        for (int s = 0; s < kTwHalfSlots; s++)
+            for (int l = 0; l < 64; l++) out[(h * kTwHalfSlots + s) * 64 + l] = base(half_slot_index(h, s, l));
+}
+BRC_HD int half_y(int lane, int r, int h) { return (r << 7) | (lane << 1) | h; }
+
+// E = C[m0], O = conj(C[511 - m0]) on entry (m0 = br3(r)<<6 | lane); level 0 and the three in-register levels
+template <int H>
+BRC_HD void half_phaseA(c64 (&v)[8], const c64 (&E)[8], const c64 (&O)[8], const PhaseAConsts &k) {
+#pragma unroll
+    for (int r = 0; r < 8; r++)  // polynomials.cpp:113-122: sum (y0 = 0) / difference (y0 = 1)
+        v[r] = H == 0 ? c64{E[r].re + O[r].re, E[r].im + O[r].im} : c64{E[r].re - O[r].re, E[r].im - O[r].im};
+    // k' = 0 (size 4): table(4, h) = 1 or -i
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        if (H == 0) inv_bf_one(v[r], v[r + 1]);
+        else inv_bf_mi(v[r], v[r + 1]);
+    }
+    // k' = 1 (size 8): table(8, 2 (r&1) + h)
+#pragma unroll
+    for (int g = 0; g < 8; g += 4) {
+        if (H == 0) {
+            inv_bf_one(v[g], v[g + 2]);
+            inv_bf_mi(v[g + 1], v[g + 3]);
+        } else {
+            inv_bf(v[g], v[g + 2], c64{k.c4, k.c4});
+            inv_bf_neg(v[g + 1], v[g + 3], k.c4, k.c4);
+        }
+    }
+    // k' = 2 (size 16): table(16, 2 (r&3) + h)
+    if (H == 0) {
+        inv_bf_one(v[0], v[4]);
+        inv_bf(v[1], v[5], c64{k.c4, k.c4});
+        inv_bf_mi(v[2], v[6]);
+        inv_bf_neg(v[3], v[7], k.c4, k.c4);
+    } else {
+        inv_bf(v[0], v[4], c64{k.c8, k.s8});
+        inv_bf(v[1], v[5], c64{k.s8, k.c8});
+        inv_bf_neg(v[2], v[6], k.s8, k.c8);
+        inv_bf_neg(v[3], v[7], k.c8, k.s8);
+    }
+}
+// three levels on the register bits; TW: (slot) -> this lane's entry of the image of this wave's h; BASE = TWH_B / TWH_C
+template <int BASE, class TW>
+BRC_HD void half_phaseBC(c64 (&v)[8], const TW &tw) {
+    {
+        const c64 w = tw(BASE + 0);
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) inv_bf(v[r], v[r + 1], w);
+    }
+    {
+        const c64 w = tw(BASE + 1);
+#pragma unroll
+        for (int g = 0; g < 8; g += 4) {
+            inv_bf(v[g], v[g + 2], w);
+            inv_bf_q(v[g + 1], v[g + 3], w);
+        }
+    }
+    {
+        const c64 a = tw(BASE + 2), b = tw(BASE + 3);
+        inv_bf(v[0], v[4], a);
+        inv_bf(v[1], v[5], b);
+        inv_bf_q(v[2], v[6], a);
+        inv_bf_q(v[3], v[7], b);
+    }
+}
+
 // last merge (size 2048) + scaling + truncation: polynomials.cpp:160-166 with E = 0, then :392.
 // BOUNDED = true may be used when |value| < 2^51 is guaranteed (inside the external product the value is a sum of
 // 6*1024 products of a digit in [-64,63] and a torus real in [-1/2,1/2), scaled by 2^32: below 2^50).  Then
@@ -444,6 +535,16 @@ BRC_HD void inv_final(int32_t (&out)[16], const c64 (&v)[16], const TW &tw) {
         const c64 w = tw(TWS_FIN + rho);
         out[rho] = scale_to_torus32<BOUNDED>(v[rho].re * w.re + v[rho].im * w.im);
         out[rho + 8] = scale_to_torus32<BOUNDED>(v[rho + 8].im * w.re - v[rho + 8].re * w.im);
+    }
+}
+// the same for the split transform: output r of lane l is coefficient half_y(l, r, h); r >= 4 (y9 = 1) is the quarter turn
+template <bool BOUNDED, class TW>
+BRC_HD void half_final(int32_t (&out)[8], const c64 (&v)[8], const TW &tw) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const c64 w = tw(TWH_FIN + r);
+        out[r] = scale_to_torus32<BOUNDED>(v[r].re * w.re + v[r].im * w.im);
+        out[r + 4] = scale_to_torus32<BOUNDED>(v[r + 4].im * w.re - v[r + 4].re * w.im);
     }
 }
 

@@ -524,23 +524,32 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kCoopWaves = kKpl;
 constexpr int kShapeCoop = 6;  // the name of this launch shape in launch_br / TFHE_HIP_BR_WAVES (whatever kKpl is)
-constexpr int kCoopLds = kTwLaneEntries * (int) sizeof(c64) + 2 * kN * 4 + kCoopWaves * 2 * kNh * (int) sizeof(c64) + 640 * 4 +
+constexpr int kTwHalfEntries = 2 * kTwHalfSlots * 64;          // image of the split inverse, both halves
+constexpr int kCoopTwEntries = 8 * 64 + kTwHalfEntries;         // forward slots 0..7 of the main image + that: 32 KB
+constexpr int kCoopLds = kCoopTwEntries * (int) sizeof(c64) + 2 * kN * 4 + kCoopWaves * 2 * kNh * (int) sizeof(c64) + 640 * 4 +
                          2 * kN * 4;
+static_assert(kCoopWaves >= 4, "the split inverse needs four waves");
+static_assert(TWS_FB == 0 && TWS_FC == 4, "the forward slots are the first eight of the main image");
 
 template <int MODE>
 __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
-    load_tw_to_lds(tw_lds, A.tw);
+    for (int i = threadIdx.x; i < kCoopTwEntries; i += 64 * kCoopWaves)  // forward slots, then the split-inverse image
+        tw_lds[i] = A.tw[i < 8 * 64 ? i : i - 8 * 64 + kTwLaneEntries];
+    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    int32_t *acc = reinterpret_cast<int32_t *>(lds_raw + kTwLaneEntries * sizeof(c64));
-    c64 *bufs = reinterpret_cast<c64 *>(lds_raw + kTwLaneEntries * sizeof(c64) + 2 * kN * 4);
+    int32_t *acc = reinterpret_cast<int32_t *>(lds_raw + kCoopTwEntries * sizeof(c64));
+    c64 *bufs = reinterpret_cast<c64 *>(lds_raw + kCoopTwEntries * sizeof(c64) + 2 * kN * 4);
     c64 *mineA = bufs + (size_t) wave * 2 * kNh, *mineB = mineA + kNh;
     const long long g = blockIdx.x;  // host launches exactly B workgroups
     const PhaseAConsts twu = A.ka;
     const TwLds twl{tw_lds + lane};
     const int c = wave >= kL ? 1 : 0, p = wave - c * kL;
+    // inverse transforms: waves 0..3, wave = 2 h + column (br_core.h "split over two waves")
+    const int icol = wave & 1, ih = (wave >> 1) & 1;
+    const TwLds twh{tw_lds + (8 + ih * kTwHalfSlots) * 64 + lane};
 
     const int32_t *ga = nullptr, *gb = nullptr;
     int32_t sa = A.sa, sb = A.sb, cst = A.cst;
@@ -602,10 +611,10 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
         return idx < kNh / 2 ? lo + idx : hi + (idx - kNh / 2);
     };
     int i = next_active(0);
-    int32_t own[16];  // waves 0 and 1: accumulator column `wave`, layout inv_yC
-    if (wave < 2) {
+    int32_t own[8];  // waves 0..3: the coefficients y = half_y(lane, r, ih) of accumulator column icol
+    if (wave < 4) {
 #pragma unroll
-        for (int rho = 0; rho < 16; rho++) own[rho] = acc[wave * kN + inv_yC(lane, rho)];
+        for (int r = 0; r < 8; r++) own[r] = acc[icol * kN + half_y(lane, r, ih)];
     }
     if (i < kLwe) prepare_diff(__builtin_amdgcn_readfirstlane(bara_lds[i]));
     __syncthreads();
@@ -650,26 +659,42 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
             *sum_slot(col, swz(x)) = t;
         }
         __syncthreads();  // summed spectra in place
-        if (wave < 2) {   // wave 0: column 0, wave 1: column 1
-            c64 x[16];
-            int32_t res[16];
+        c64 E[8], O[8];
+        if (wave < 4) {  // level-0 operands of this wave's half, straight from the summed spectrum
 #pragma unroll
-            for (int rho = 0; rho < 16; rho++) {  // as spectrum_to_inv_input, reading the summed spectrum
-                const int m = (br4(rho) << 6) | lane;
-                if (br4(rho) < 8) {
-                    x[rho] = *sum_slot(wave, swz(gray(m)));
-                } else {
-                    const c64 t = *sum_slot(wave, swz(gray(1023 - m)));
-                    x[rho] = {t.re, -t.im};
-                }
+            for (int r = 0; r < 8; r++) {
+                const int m0 = (br3(r) << 6) | lane;
+                E[r] = *sum_slot(icol, swz(gray(m0)));
+                const c64 t = *sum_slot(icol, swz(gray(511 - m0)));
+                O[r] = {t.re, -t.im};
             }
-            wave_sync();
-            wave_inv<true>(res, x, lane, wave == 0 ? mineA : mineB, twu, twl);
-            int32_t *dst = acc + wave * kN;
+        }
+        __syncthreads();  // both halves of a column have read the spectrum that lies over its accumulator mirror
+        if (wave < 4) {
+            c64 v[8];
+            int32_t res[8];
+            if (ih == 0) half_phaseA<0>(v, E, O, twu);
+            else half_phaseA<1>(v, E, O, twu);
 #pragma unroll
-            for (int rho = 0; rho < 16; rho++) {  // tLweAddTo (tlwe-functions.cpp:149)
-                own[rho] = (int32_t) ((uint32_t) own[rho] + (uint32_t) res[rho]);
-                dst[inv_yC(lane, rho)] = own[rho];
+            for (int r = 0; r < 8; r++) mineA[swz(fwd_xA(lane, r))] = v[r];
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 8; r++) v[r] = mineA[swz(fwd_xB(lane, r))];
+            wave_sync();
+            half_phaseBC<TWH_B>(v, twh);
+#pragma unroll
+            for (int r = 0; r < 8; r++) mineA[swz(fwd_xB(lane, r))] = v[r];
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 8; r++) v[r] = mineA[swz(fwd_xC(lane, r))];
+            wave_sync();
+            half_phaseBC<TWH_C>(v, twh);
+            half_final<true>(res, v, twh);
+            int32_t *dst = acc + icol * kN;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {  // tLweAddTo (tlwe-functions.cpp:149)
+                own[r] = (int32_t) ((uint32_t) own[r] + (uint32_t) res[r]);
+                dst[half_y(lane, r, ih)] = own[r];
             }
         }
         __syncthreads();  // accumulator updated
@@ -1513,8 +1538,10 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     std::vector<c64> image(kTwLaneEntries);
     build_lane_twiddles(image.data(), [&](int i) { return tw[i]; });
-    if (e == hipSuccess) e = hipMalloc((void **) &c->tw, kTwLaneEntries * sizeof(c64));
-    if (e == hipSuccess) e = hipMemcpy(c->tw, image.data(), kTwLaneEntries * sizeof(c64), hipMemcpyHostToDevice);
+    image.resize(kTwLaneEntries + kTwHalfEntries);  // followed by the image of the split inverse (latency kernel)
+    build_half_twiddles(image.data() + kTwLaneEntries, [&](int i) { return tw[i]; });
+    if (e == hipSuccess) e = hipMalloc((void **) &c->tw, image.size() * sizeof(c64));
+    if (e == hipSuccess) e = hipMemcpy(c->tw, image.data(), image.size() * sizeof(c64), hipMemcpyHostToDevice);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e != hipSuccess) {
         tfhe_hip_destroy(c);
