@@ -514,20 +514,35 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
 // ---------------------------------------------------------------------------------------------------------------
 // blind rotation, latency shape: ONE WORKGROUP (6 waves) per ciphertext, for batches that cannot fill the chip.
 // Per CMux: wave w transforms decomposition row w (column c = w/3, digit p = w%3) and multiplies it with key row w;
-// the six products P_w are summed in row order by the two waves that then run the two inverse transforms -
-// ((((P_0 + P_1) + P_2) + P_3) + P_4) + P_5 with P_w rounded on its own is exactly what the reference's
-// clear-then-AddMul loop computes (tgsw-fft-operations.cpp:108-114), so results stay bit-identical.
-// Critical path per CMux: one forward + one inverse transform instead of six + two.
-// LDS: twiddle image | accumulator 8 KB | per wave: A (scratch, then product column 0) 8 KB, B (product column 1) 8 KB
+// the 2l products P_w are summed in row order by all threads - ((((P_0 + P_1) + P_2) + P_3) + P_4) + P_5 with P_w
+// rounded on its own is exactly what the reference's clear-then-AddMul loop computes (tgsw-fft-operations.cpp:108-114),
+// so results stay bit-identical.  Critical path per CMux: one forward + half an inverse transform instead of six + two.
+// The two inverse transforms run on four waves, two per column (br_core.h "split over two waves").
+// LDS: twiddle image (forward slots + split-inverse image, 32 KB) | accumulator 8 KB
+//      | per wave: A (scratch, then product column 0) 8 KB, B (product column 1) 8 KB
 //      | the 630 rotation amounts (computed once, so that no global load sits on the per-iteration critical path)
 //      | prepared differences 8 KB (see prepare_diff)
 // ---------------------------------------------------------------------------------------------------------------
+template <int BASE>
+struct TwReg4 {  // four twiddles of one phase held in registers
+    c64 t[4];
+    __device__ __forceinline__ c64 operator()(int slot) const { return t[slot - BASE]; }
+};
 constexpr int kCoopWaves = kKpl;
+// Key row requested one iteration ahead (it then arrives during the sum and the inverse transforms): one gate
+// 3.39 -> 3.23 ms with six waves, where waves 4 and 5 idle during the inverse; 2.46 -> 2.59 ms with four waves, where
+// every wave carries the 64 key registers through its inverse transform.
+#ifdef COOP_KEY_AHEAD
+constexpr bool kCoopKeyAhead = COOP_KEY_AHEAD;
+#else
+constexpr bool kCoopKeyAhead = kCoopWaves > 4;
+#endif
 constexpr int kShapeCoop = 6;  // the name of this launch shape in launch_br / TFHE_HIP_BR_WAVES (whatever kKpl is)
 constexpr int kTwHalfEntries = 2 * kTwHalfSlots * 64;          // image of the split inverse, both halves
 constexpr int kCoopTwEntries = 8 * 64 + kTwHalfEntries;         // forward slots 0..7 of the main image + that: 32 KB
 constexpr int kCoopLds = kCoopTwEntries * (int) sizeof(c64) + 2 * kN * 4 + kCoopWaves * 2 * kNh * (int) sizeof(c64) + 640 * 4 +
                          2 * kN * 4;
+static_assert(kCoopLds <= 160 * 1024, "LDS of one CU");
 static_assert(kCoopWaves >= 4, "the split inverse needs four waves");
 static_assert(TWS_FB == 0 && TWS_FC == 4, "the forward slots are the first eight of the main image");
 
@@ -605,7 +620,8 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
     };
     // The summed spectrum of column `col` (512 values, 8 KB) lies, between the sum and the start of the inverse
     // transform, over that column's accumulator mirror and difference buffer (4 KB each): both are dead in that
-    // window and are rewritten before their next use.
+    // window and are rewritten before their next use.  (Giving the first half a buffer of its own, which makes the
+    // barrier after the spectrum reads unnecessary, measured slower: 3.35 against 3.18 ms per gate.)
     auto sum_slot = [&](int col, int idx) -> c64 * {
         c64 *lo = reinterpret_cast<c64 *>(acc + col * kN), *hi = reinterpret_cast<c64 *>(diff + col * kN);
         return idx < kNh / 2 ? lo + idx : hi + (idx - kNh / 2);
@@ -619,14 +635,18 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
     if (i < kLwe) prepare_diff(__builtin_amdgcn_readfirstlane(bara_lds[i]));
     __syncthreads();
 
-#pragma unroll 1
-    while (i < kLwe) {
-        const c64 *row = A.bk + ((size_t) i * kKpl + wave) * 2 * kNh + lane;
-        c64 kb[2][8];
+    auto load_key_row = [&](c64 (&kb)[2][8], int it) {  // key row `wave` of TGSW sample `it`: 16 coalesced 1 KB loads
+        const c64 *row = A.bk + ((size_t) it * kKpl + wave) * 2 * kNh + lane;
 #pragma unroll
         for (int c2 = 0; c2 < 2; c2++)
 #pragma unroll
             for (int r = 0; r < 8; r++) kb[c2][r] = row[c2 * kNh + r * 64];
+    };
+    c64 kb[2][8];
+    if (kCoopKeyAhead && i < kLwe) load_key_row(kb, i);
+#pragma unroll 1
+    while (i < kLwe) {
+        if (!kCoopKeyAhead) load_key_row(kb, i);
         c64 v[8];
         const uint32_t *dcol = diff + c * kN + lane;
 #pragma unroll
@@ -644,6 +664,7 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
             mineB[r * 64 + lane] = {ac1 - bd1, ad1 + bc1};
         }
         const int inext = next_active(i + 1);
+        if (kCoopKeyAhead && inext < kLwe) load_key_row(kb, inext);  // arrives during the sum and the inverse transforms
         __syncthreads();  // all six products in LDS; every wave is done reading the differences
         // sum over the rows, in row order, by all threads: element e = (column, physical slot x)
         for (int e = threadIdx.x; e < 2 * kNh; e += 64 * kCoopWaves) {
@@ -673,23 +694,34 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
         if (wave < 4) {
             c64 v[8];
             int32_t res[8];
+            // the twiddles of each phase are requested before the transpose that precedes it
+            TwReg4<TWH_B> tb;
+            TwReg4<TWH_C> tc;
+            TwReg4<TWH_FIN> tf;
+#pragma unroll
+            for (int q = 0; q < 4; q++) tb.t[q] = twh(TWH_B + q);
+            wave_sync();
             if (ih == 0) half_phaseA<0>(v, E, O, twu);
             else half_phaseA<1>(v, E, O, twu);
 #pragma unroll
             for (int r = 0; r < 8; r++) mineA[swz(fwd_xA(lane, r))] = v[r];
             wave_sync();
 #pragma unroll
+            for (int q = 0; q < 4; q++) tc.t[q] = twh(TWH_C + q);
+#pragma unroll
             for (int r = 0; r < 8; r++) v[r] = mineA[swz(fwd_xB(lane, r))];
             wave_sync();
-            half_phaseBC<TWH_B>(v, twh);
+            half_phaseBC<TWH_B>(v, tb);
 #pragma unroll
             for (int r = 0; r < 8; r++) mineA[swz(fwd_xB(lane, r))] = v[r];
             wave_sync();
 #pragma unroll
+            for (int q = 0; q < 4; q++) tf.t[q] = twh(TWH_FIN + q);
+#pragma unroll
             for (int r = 0; r < 8; r++) v[r] = mineA[swz(fwd_xC(lane, r))];
             wave_sync();
-            half_phaseBC<TWH_C>(v, twh);
-            half_final<true>(res, v, twh);
+            half_phaseBC<TWH_C>(v, tc);
+            half_final<true>(res, v, tf);
             int32_t *dst = acc + icol * kN;
 #pragma unroll
             for (int r = 0; r < 8; r++) {  // tLweAddTo (tlwe-functions.cpp:149)
