@@ -529,14 +529,11 @@ struct TwReg4 {  // four twiddles of one phase held in registers
     __device__ __forceinline__ c64 operator()(int slot) const { return t[slot - BASE]; }
 };
 constexpr int kCoopWaves = kKpl;
-// Key row requested one iteration ahead (it then arrives during the sum and the inverse transforms): one gate
-// 3.39 -> 3.23 ms with six waves, where waves 4 and 5 idle during the inverse; 2.46 -> 2.59 ms with four waves, where
-// every wave carries the 64 key registers through its inverse transform.
-#ifdef COOP_KEY_AHEAD
-constexpr bool kCoopKeyAhead = COOP_KEY_AHEAD;
-#else
-constexpr bool kCoopKeyAhead = kCoopWaves > 4;
-#endif
+// Key rows: waves 4 and up (which idle during the inverse transforms) request the row of the next iteration right
+// after the row sum, so it is there when their forward transform ends - they share a SIMD with an older wave and are
+// the slower ones (5.9 k against 4.1 k cycles per forward step); waves 0..3 request theirs at the top of the iteration
+// and have slack before the barrier.  (All waves requesting ahead: 3.39 -> 3.23 ms per gate with six waves, but the 64
+// key registers carried through the inverse transform leave no room for anything else: 2.46 -> 2.59 ms with four.)
 constexpr int kShapeCoop = 6;  // the name of this launch shape in launch_br / TFHE_HIP_BR_WAVES (whatever kKpl is)
 constexpr int kTwHalfEntries = 2 * kTwHalfSlots * 64;          // image of the split inverse, both halves
 constexpr int kCoopTwEntries = 8 * 64 + kTwHalfEntries;         // forward slots 0..7 of the main image + that: 32 KB
@@ -612,10 +609,25 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
     };
     // all threads: diff = decomp_prepare((X^a - 1) * ACC) for the coming iteration (torusPolynomialMulByXaiMinusOne,
     // toruspolynomial-functions.cpp:106-124), so that the forward waves only read, extract their digit and convert
+    // (all reads first, then all writes: a write between two reads would stop the compiler from overlapping their
+    //  LDS latencies, since it cannot know that `diff` and `acc` do not overlap; measured together with the same change
+    //  to the row sum below: see DESIGN.md 4.1)
+    constexpr int kCoopThreads = 64 * kCoopWaves;
     auto prepare_diff = [&](int a) {
-        for (int e = threadIdx.x; e < 2 * kN; e += 64 * kCoopWaves) {
-            const int32_t *col = acc + (e & kN);
-            diff[e] = decomp_prepare(rot_minus_one(col, a, e & (kN - 1)));
+        constexpr int kIter = (2 * kN + kCoopThreads - 1) / kCoopThreads, kGroup = kIter > 6 ? kIter : 3;  // register room: four waves 8 of 8, six waves 3 of 6
+#pragma unroll
+        for (int k0 = 0; k0 < kIter; k0 += kGroup) {
+            uint32_t tmp[kGroup];
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                const int e = threadIdx.x + (k0 + k) * kCoopThreads;
+                if (e < 2 * kN) tmp[k] = decomp_prepare(rot_minus_one(acc + (e & kN), a, e & (kN - 1)));
+            }
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                const int e = threadIdx.x + (k0 + k) * kCoopThreads;
+                if (e < 2 * kN) diff[e] = tmp[k];
+            }
         }
     };
     // The summed spectrum of column `col` (512 values, 8 KB) lies, between the sum and the start of the inverse
@@ -643,10 +655,10 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
             for (int r = 0; r < 8; r++) kb[c2][r] = row[c2 * kNh + r * 64];
     };
     c64 kb[2][8];
-    if (kCoopKeyAhead && i < kLwe) load_key_row(kb, i);
+    if (wave >= 4 && i < kLwe) load_key_row(kb, i);
 #pragma unroll 1
     while (i < kLwe) {
-        if (!kCoopKeyAhead) load_key_row(kb, i);
+        if (wave < 4) load_key_row(kb, i);
         c64 v[8];
         const uint32_t *dcol = diff + c * kN + lane;
 #pragma unroll
@@ -664,34 +676,56 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
             mineB[r * 64 + lane] = {ac1 - bd1, ad1 + bc1};
         }
         const int inext = next_active(i + 1);
-        if (kCoopKeyAhead && inext < kLwe) load_key_row(kb, inext);  // arrives during the sum and the inverse transforms
         __syncthreads();  // all six products in LDS; every wave is done reading the differences
         // sum over the rows, in row order, by all threads: element e = (column, physical slot x)
-        for (int e = threadIdx.x; e < 2 * kNh; e += 64 * kCoopWaves) {
-            const int col = e >> 9, x = e & (kNh - 1);
-            const c64 *src = bufs + (size_t) col * kNh + x;
-            c64 t = src[0];
+        if constexpr (kCoopWaves > 4) {  // six waves: no register room for more than one element at a time
+            for (int e = threadIdx.x; e < 2 * kNh; e += kCoopThreads) {
+                const int col = e >> 9, x = e & (kNh - 1);
+                const c64 *src = bufs + (size_t) col * kNh + x;
+                c64 t = src[0];
 #pragma unroll
-            for (int w = 1; w < kCoopWaves; w++) {
-                const c64 u = src[(size_t) w * 2 * kNh];
-                t.re += u.re;
-                t.im += u.im;
+                for (int w = 1; w < kCoopWaves; w++) {
+                    const c64 u = src[(size_t) w * 2 * kNh];
+                    t.re += u.re;
+                    t.im += u.im;
+                }
+                *sum_slot(col, swz(x)) = t;
             }
-            *sum_slot(col, swz(x)) = t;
+        } else {  // four waves: all reads first, as in prepare_diff (2.28 -> 2.18 ms per gate)
+            constexpr int kIter = 2 * kNh / kCoopThreads;
+            c64 t[kIter];
+#pragma unroll
+            for (int k = 0; k < kIter; k++) {
+                const int e = threadIdx.x + k * kCoopThreads;
+                const c64 *src = bufs + (size_t) (e >> 9) * kNh + (e & (kNh - 1));
+                t[k] = src[0];
+#pragma unroll
+                for (int w = 1; w < kCoopWaves; w++) {
+                    const c64 u = src[(size_t) w * 2 * kNh];
+                    t[k].re += u.re;
+                    t[k].im += u.im;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kIter; k++) {
+                const int e = threadIdx.x + k * kCoopThreads;
+                *sum_slot(e >> 9, swz(e & (kNh - 1))) = t[k];
+            }
         }
         __syncthreads();  // summed spectra in place
-        c64 E[8], O[8];
-        if (wave < 4) {  // level-0 operands of this wave's half, straight from the summed spectrum
+        if (wave >= 4) {  // (a branch of its own, so that the key registers are not live across the inverse transform)
+            if (inext < kLwe) load_key_row(kb, inext);  // arrives during the inverse transforms
+            __syncthreads();  // the same barrier as in the other branch
+        } else {
+            c64 E[8], O[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
+            for (int r = 0; r < 8; r++) {  // level-0 operands of this wave's half, straight from the summed spectrum
                 const int m0 = (br3(r) << 6) | lane;
                 E[r] = *sum_slot(icol, swz(gray(m0)));
                 const c64 t = *sum_slot(icol, swz(gray(511 - m0)));
                 O[r] = {t.re, -t.im};
             }
-        }
-        __syncthreads();  // both halves of a column have read the spectrum that lies over its accumulator mirror
-        if (wave < 4) {
+            __syncthreads();  // both halves of a column have read the spectrum that lies over its accumulator mirror
             c64 v[8];
             int32_t res[8];
             // the twiddles of each phase are requested before the transpose that precedes it
