@@ -1472,9 +1472,12 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
     // waves per workgroup: 8 (two per SIMD) is the throughput shape.  Batches that cannot fill the chip that way run
     // with fewer waves per CU, which finish sooner (measured per wave: 8 per CU 16.4 ms, 4 per CU 10.5 ms, alone 8.8 ms)
     int waves = c->br_waves;
-    // (measured: 512 gates 7.7 ms as two rounds of the latency kernel against 9.6 ms with 4 waves per workgroup;
-    //  640 gates 11.4 ms against 9.6 ms)
-    if (waves == 0) waves = A.B <= 512 ? (MODE == MODE_EXTMUL ? (A.B <= 256 ? 1 : 4) : kShapeCoop) : A.B <= 1024 ? 4 : 8;
+    // (measured, default set, ms for 256 / 512 / 768 / 1024 / 1536 gates: latency kernel 3.3 / 6.1 / 9.0 / 12.0 / 18.0,
+    //  4 waves per workgroup 9.5 / 9.6 / 9.7 / 9.8 / 19.6, 8 waves 13.9 / 14.0 / 14.1 / 14.2 / 14.2; tools/shape_bench.py)
+    constexpr long long kCoopMax = kCoopWaves > 4 ? 768 : 512;  // rounds of 256 workgroups that still beat 4 waves
+    if (waves == 0)
+        waves = MODE == MODE_EXTMUL ? (A.B <= 256 ? 1 : A.B <= 1024 ? 4 : 8)
+                                    : (A.B <= kCoopMax ? kShapeCoop : A.B <= 1024 ? 4 : 8);
     if (waves == kShapeCoop && MODE != MODE_EXTMUL) {  // one workgroup per ciphertext (latency shape)
         HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate_coop<MODE == MODE_EXTMUL ? MODE_RAW : MODE>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kCoopLds));
