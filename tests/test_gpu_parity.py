@@ -322,3 +322,19 @@ def test_bootstrapping_key_generated_on_the_gpu(client, keys, engine):
         print("keygen_bk %.3f s" % dt)
     finally:
         e2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count", [257, 700, 769, 1025])
+def test_batch_sizes_around_the_launch_shape_thresholds(count, engine, client, keys, oracle, okeys):
+    """launch_br picks the latency kernel up to 768 gates (one to three rounds of 256 workgroups), 4 waves per workgroup
+    up to 1,024 and 8 above; sizes next to the thresholds, with ragged last rounds / workgroups: every output decrypts,
+    a sample of them equals the reference's ciphertexts"""
+    rng = np.random.default_rng(count)
+    bits = rng.integers(0, 2, (2, count)).astype(np.uint8)
+    a, b = client.encrypt(keys, bits[0], seed=60), client.encrypt(keys, bits[1], seed=61)
+    out = engine.gate_batch(Gate.ANDNY, a, b)
+    assert np.array_equal(client.decrypt(keys, out)[0], TRUTH[int(Gate.ANDNY)](bits[0], bits[1], None))
+    pick = np.array([0, 255, 256, count // 2, count - 2, count - 1])
+    want = oracle.gate_batch(okeys, Gate.ANDNY, a[pick], b[pick], None, nthreads=6)
+    assert np.array_equal(out[pick], want)
