@@ -563,7 +563,12 @@ BRC_HD int32_t rot_minus_one(const int32_t *acc, int a, int j) {
 // coefficient cost one add, one xor (decomp_prepare, once) and one signed bit-field extract each (decomp_digit).
 BRC_HD uint32_t decomp_prepare(int32_t t) { return ((uint32_t) t + kDecompOffset) ^ kDecompOffset; }
 BRC_HD int32_t decomp_digit(uint32_t prepared, int p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one v_bfe_i32 also when p is not a compile-time constant (the shift pair costs two instructions then)
+    return __builtin_amdgcn_sbfe((int32_t) prepared, 32 - kBgbit * (p + 1), kBgbit);
+#else
     return ((int32_t) (prepared << (kBgbit * p))) >> (32 - kBgbit);
+#endif
 }
 // modSwitchFromTorus32(x, 2N): reference numeric-functions.cpp:59-65 (2^64/2N = 2^53 wide intervals)
 BRC_HD int32_t modswitch_2N(int32_t x) { return (int32_t) ((((uint32_t) x) + (1u << 20)) >> 21) & (2 * kN - 1); }
