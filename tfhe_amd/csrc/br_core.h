@@ -563,11 +563,16 @@ BRC_HD int32_t rot_minus_one(const int32_t *acc, int a, int j) {
 // coefficient cost one add, one xor (decomp_prepare, once) and one signed bit-field extract each (decomp_digit).
 BRC_HD uint32_t decomp_prepare(int32_t t) { return ((uint32_t) t + kDecompOffset) ^ kDecompOffset; }
 BRC_HD int32_t decomp_digit(uint32_t prepared, int p) {
+    return ((int32_t) (prepared << (kBgbit * p))) >> (32 - kBgbit);
+}
+// the same as one v_bfe_i32 when p is not a compile-time constant (the shift pair costs two instructions then).  Used
+// by the throughput kernel (-96 VALU instructions per CMux, +0.3 % measured); the latency kernel, whose register
+// allocation sits at the limit, measured 3.7 % slower with it and keeps the shifts.
+BRC_HD int32_t decomp_digit_rt(uint32_t prepared, int p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // one v_bfe_i32 also when p is not a compile-time constant (the shift pair costs two instructions then)
     return __builtin_amdgcn_sbfe((int32_t) prepared, 32 - kBgbit * (p + 1), kBgbit);
 #else
-    return ((int32_t) (prepared << (kBgbit * p))) >> (32 - kBgbit);
+    return decomp_digit(prepared, p);
 #endif
 }
 // modSwitchFromTorus32(x, 2N): reference numeric-functions.cpp:59-65 (2^64/2N = 2^53 wide intervals)

@@ -278,7 +278,7 @@ __device__ __forceinline__ void fwd_step(const int t, c64 (&v)[8], const c64 (&p
         }
     }
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = {(double) decomp_digit(tlo[r], p), (double) decomp_digit(thi[r], p)};
+    for (int r = 0; r < 8; r++) v[r] = {(double) decomp_digit_rt(tlo[r], p), (double) decomp_digit_rt(thi[r], p)};
     // one 8-value key buffer in rotation: holds (row t-1, column 0) on entry, (row t-1, column 1) between the two
     // gaps, (row t, column 0) on exit
     const c64 *row = bki + (size_t) (t * 2) * kNh + lane;
