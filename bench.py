@@ -121,8 +121,10 @@ def side_bench(args, torch, dev, rank, world):
 
 def adder_bench(args, torch, dev, eng):
     """BASELINE configs[3]: W independent 32-bit ripple-carry adders, the reference's full_adder_MUX gate sequence
-    (src/test/test-addition-boot.cpp:30-67), levelized; every level is one call on a device-resident ciphertext pool
-    (tfhe_hip_gate_level_dev).  The reference evaluates the same circuit as 32 x 4 sequential gate calls."""
+    (src/test/test-addition-boot.cpp:30-67), levelized over a device-resident ciphertext pool and compiled once
+    (tfhe_hip_netlist_create: validation, job upload, one hipGraph over all levels); a step is one replay.
+    TFHE_BENCH_LEVEL_BY_LEVEL=1 runs one tfhe_hip_gate_level_dev call per level instead.
+    The reference evaluates the same circuit as 32 x 4 sequential gate calls."""
     from tfhe_amd import Client, Gate, PARAMS as PR
     from tfhe_amd.netlist import Netlist, full_adder_mux
     W, nbits = args.instances, 32
@@ -149,9 +151,15 @@ def adder_bench(args, torch, dev, eng):
     ngates = sum(int((lv[:, 0] <= int(Gate.MUX)).sum()) for lv in levels)
     nboot = sum(int((lv[:, 0] < int(Gate.MUX)).sum()) + 2 * int((lv[:, 0] == int(Gate.MUX)).sum()) for lv in levels)
 
+    by_level = os.environ.get("TFHE_BENCH_LEVEL_BY_LEVEL") == "1"
+    compiled = None if by_level else eng.netlist_create(pool, rows, levels)
+
     def run():
-        for lv in levels:
-            eng.gate_level_dev(pool, rows, lv)
+        if by_level:
+            for lv in levels:
+                eng.gate_level_dev(pool, rows, lv)
+        else:
+            compiled.run(sync=False)
 
     for _ in range(args.warmup):
         run()
@@ -170,8 +178,12 @@ def adder_bench(args, torch, dev, eng):
                       "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "f64",
                       "data": "synthetic",
                       "config": {"workload": "adder", "instances": W, "bits": nbits, "levels": len(levels),
+                                 "evaluation": "level by level" if by_level else
+                                 ("compiled netlist, hipGraph" if compiled.is_graph else "compiled netlist, direct enqueue"),
                                  "gates_per_step": ngates, "bootstraps_per_step": nboot,
                                  "additions_per_s": W / dt, "sums_decrypt_correctly": True}}), flush=True)
+    if compiled is not None:
+        compiled.close()
     eng.close()
 
 

@@ -170,6 +170,22 @@ int tfhe_hip_negacyclic_mul2048_batch(tfhe_hip_ctx *ctx, int32_t *out, const int
 int tfhe_hip_negacyclic_mul2048_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_ipolys,
                                           const int32_t *d_tpolys, int64_t count);
 
+/* ---- compiled netlist (levels without host round-trips) ---------------------------------------
+ * A whole levelized circuit over a device-resident pool: `gates` holds the levels back to back ({gate, out, a, b, c}
+ * rows as for tfhe_hip_gate_level_dev), level_counts[l] the number of gates of level l.  Every level is validated
+ * against the level contract at creation, the job lists are uploaded once, and the launches of all levels are
+ * recorded into one hipGraph bound to d_pool (if the runtime cannot capture them, run enqueues them one by one -
+ * tfhe_hip_netlist_is_graph tells which).  tfhe_hip_netlist_run is asynchronous on the context's stream
+ * (tfhe_hip_sync waits); it may be called any number of times, e.g. after new inputs were written to the pool.
+ * A netlist is tied to its context and pool; destroy it before either.  Runs of one context are stream-ordered.
+ * The reference has no counterpart: its applications call bootsXXX gate by gate (src/test/test-addition-boot.cpp). */
+typedef struct tfhe_hip_netlist tfhe_hip_netlist;
+int tfhe_hip_netlist_create(tfhe_hip_ctx *ctx, tfhe_hip_netlist **out, int32_t *d_pool, int64_t pool_rows,
+                            const int32_t *gates, const int64_t *level_counts, int64_t nlevels);
+int tfhe_hip_netlist_run(tfhe_hip_netlist *netlist);
+int tfhe_hip_netlist_is_graph(const tfhe_hip_netlist *netlist);
+void tfhe_hip_netlist_destroy(tfhe_hip_netlist *netlist);
+
 /* the parameter set this library was built for: out = {lambda, n, N, k, l, Bgbit, ks_t, ks_basebit} */
 void tfhe_hip_param_set(int32_t out[8]);
 

@@ -117,3 +117,49 @@ def test_long_run_of_random_gates(engine, client, keys):
             resid = np.abs(np.abs(phases.astype(np.int64)) - (1 << 29)).reshape(W, R)[fresh]
             assert resid.max() < (1 << 28), resid.max()
     engine.dev_free(d_pool)
+
+
+@pytest.mark.gpu
+def test_compiled_netlist_equals_level_by_level(engine, client, keys):
+    """tfhe_hip_netlist_*: the whole circuit validated and uploaded once, replayed as one hipGraph (or, where the
+    runtime cannot capture, enqueued without host round-trips).  Same pool contents, bit for bit, as the level-by-level
+    path; a second run on fresh inputs in the same pool works; contract violations are caught at creation."""
+    from tfhe_amd import TfheHipError
+    nbits, W = 8, 6
+    nl = build("addmux", nbits)
+    rng = np.random.default_rng(77)
+
+    def fresh_pool(seed):
+        xs = rng.integers(0, 1 << nbits, W, dtype=np.int64)
+        ys = rng.integers(0, 1 << nbits, W, dtype=np.int64)
+        pool = np.zeros((W * nl.n_wires, P.n + 1), np.int32)
+        for k in range(W):
+            xb = ((xs[k] >> np.arange(nbits)) & 1).astype(np.uint8)
+            yb = ((ys[k] >> np.arange(nbits)) & 1).astype(np.uint8)
+            pool[k * nl.n_wires + np.array(nl.inputs["x"])] = client.encrypt(keys, xb, seed=seed + 2 * k)
+            pool[k * nl.n_wires + np.array(nl.inputs["y"])] = client.encrypt(keys, yb, seed=seed + 2 * k + 1)
+        return pool, xs, ys
+
+    levels = nl.level_arrays(instances=W)
+    d_a, d_b = engine.dev_alloc(W * nl.n_wires * (P.n + 1) * 4), engine.dev_alloc(W * nl.n_wires * (P.n + 1) * 4)
+    compiled = engine.netlist_create(d_b, W * nl.n_wires, levels)
+    print("hipGraph" if compiled.is_graph else "direct enqueue", "levels", len(levels), "bootstrapped gates", compiled.n_bootstrapped)
+    for seed in (300, 400):
+        pool, xs, ys = fresh_pool(seed)
+        engine.to_dev(d_a, pool)
+        engine.to_dev(d_b, pool)
+        nl.evaluate(lambda lv: engine.gate_level_dev(d_a, pool.shape[0], lv), instances=W)
+        compiled.run()
+        ra, rb = engine.from_dev(d_a, pool.shape), engine.from_dev(d_b, pool.shape)
+        assert np.array_equal(ra, rb)
+        for k in range(W):
+            bits, _ = client.decrypt(keys, rb[k * nl.n_wires + np.array(nl.outputs["out"])])
+            assert int(sum(int(b) << i for i, b in enumerate(bits))) == int(xs[k] + ys[k])
+    compiled.close()
+    with pytest.raises(TfheHipError):   # second level reads and writes row 1
+        engine.netlist_create(d_b, 4, [[[0, 2, 0, 1, -1]], [[0, 1, 1, 2, -1]]])
+    empty = engine.netlist_create(d_b, 4, [])
+    empty.run()
+    empty.close()
+    engine.dev_free(d_a)
+    engine.dev_free(d_b)

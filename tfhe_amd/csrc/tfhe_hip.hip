@@ -19,6 +19,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <memory>
 #include <vector>
 #include "br_core.h"
 #include "internal.h"
@@ -2103,11 +2104,9 @@ int tfhe_hip_phase_batch(tfhe_hip_ctx *c, int32_t *phases, const int32_t *lwe_ke
 }
 
 // ---- netlist level on a device-resident ciphertext pool ---------------------------------------
-int tfhe_hip_gate_level_dev(tfhe_hip_ctx *c, int32_t *d_pool, int64_t pool_rows, const int32_t *gates, int64_t count) {
-    if (int r = check_ctx(c, true)) return r;
-    if (count < 0 || pool_rows < 0 || (count > 0 && (!d_pool || !gates))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
-    c->ev_br = c->ev_ks = false;
-    if (count == 0) return TFHE_HIP_OK;
+// validates one level against the level contract and expands it into bootstrap / keyswitch / linear jobs
+// (c->h_br, c->h_ks, c->h_lin)
+static int expand_level(tfhe_hip_ctx *c, int64_t pool_rows, const int32_t *gates, int64_t count) {
     // validation: indices in range; a level reads the pool as it was before the call, so no row may be both
     // written and read (or written twice) within one level
     c->h_mark.assign((size_t) pool_rows, 0);
@@ -2143,6 +2142,15 @@ int tfhe_hip_gate_level_dev(tfhe_hip_ctx *c, int32_t *d_pool, int64_t pool_rows,
             c->h_lin.push_back(d[0]); c->h_lin.push_back(d[1]); c->h_lin.push_back(d[2]);
         }
     }
+    return TFHE_HIP_OK;
+}
+
+int tfhe_hip_gate_level_dev(tfhe_hip_ctx *c, int32_t *d_pool, int64_t pool_rows, const int32_t *gates, int64_t count) {
+    if (int r = check_ctx(c, true)) return r;
+    if (count < 0 || pool_rows < 0 || (count > 0 && (!d_pool || !gates))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    c->ev_br = c->ev_ks = false;
+    if (count == 0) return TFHE_HIP_OK;
+    if (int r = expand_level(c, pool_rows, gates, count)) return r;
     const long long nbr = (long long) c->h_br.size(), nks = (long long) c->h_ks.size(), nlin = (long long) c->h_lin.size() / 3;
     if (nlin) {
         HIPCHK(c->jobs_lin.reserve(c->h_lin.size() * sizeof(int32_t)));
@@ -2173,6 +2181,135 @@ int tfhe_hip_gate_level_dev(tfhe_hip_ctx *c, int32_t *d_pool, int64_t pool_rows,
     HIPCHK(hipStreamSynchronize(c->stream));
     return TFHE_HIP_OK;
 }
+
+// ---- compiled netlist: all levels of a circuit resident on the device, replayed as one hipGraph -------------------
+struct tfhe_hip_netlist {
+    tfhe_hip_ctx *c = nullptr;
+    int32_t *d_pool = nullptr;
+    struct Level {
+        long long nbr, nks, nlin;
+        size_t obr, oks, olin;  // element offsets into the job arrays
+    };
+    std::vector<Level> levels;
+    DevBuf jobs_br, jobs_ks, jobs_lin, ext, abart, ks_part;  // job arrays and the workspace the graph's kernels use
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+// every launch of the circuit, in level order, on the context's stream; no host synchronisation in between
+static int netlist_enqueue(tfhe_hip_netlist *nl) {
+    tfhe_hip_ctx *c = nl->c;
+    std::swap(c->abart, nl->abart);  // launch_ks takes its workspace from the context: lend it the netlist's
+    std::swap(c->ks_part, nl->ks_part);
+    int r = TFHE_HIP_OK;
+    for (const tfhe_hip_netlist::Level &lv : nl->levels) {
+        if (lv.nlin) {
+            hipLaunchKernelGGL(k_linear_level, dim3((unsigned) lv.nlin), dim3(256), 0, c->stream, nl->d_pool,
+                               (const int32_t *) nl->jobs_lin.p + lv.olin, kMU, lv.nlin);
+        }
+        if (lv.nbr) {
+            BrArgs A{};
+            A.jobs = (const BrJob *) nl->jobs_br.p + lv.obr; A.a = nl->d_pool; A.mu = kMU; A.out = (int32_t *) nl->ext.p;
+            A.bk = c->bk; A.tw = c->tw; A.ka = c->ka; A.B = lv.nbr;
+            if ((r = launch_br<MODE_GATE>(c, A))) break;
+            if ((r = launch_ks(c, nl->d_pool, (const int32_t *) nl->ext.p, lv.nks, (const KsJob *) nl->jobs_ks.p + lv.oks))) break;
+        }
+    }
+    std::swap(c->abart, nl->abart);
+    std::swap(c->ks_part, nl->ks_part);
+    return r;
+}
+
+void tfhe_hip_netlist_destroy(tfhe_hip_netlist *nl) {
+    if (!nl) return;
+    if (nl->c) {
+        (void) hipSetDevice(nl->c->device);
+        (void) hipStreamSynchronize(nl->c->stream);
+    }
+    if (nl->exec) (void) hipGraphExecDestroy(nl->exec);
+    if (nl->graph) (void) hipGraphDestroy(nl->graph);
+    nl->jobs_br.release(); nl->jobs_ks.release(); nl->jobs_lin.release();
+    nl->ext.release(); nl->abart.release(); nl->ks_part.release();
+    delete nl;
+}
+
+int tfhe_hip_netlist_create(tfhe_hip_ctx *c, tfhe_hip_netlist **out, int32_t *d_pool, int64_t pool_rows,
+                            const int32_t *gates, const int64_t *level_counts, int64_t nlevels) {
+    if (int r = check_ctx(c, true)) return r;
+    if (!out) return fail(TFHE_HIP_ERR_ARG, "null output");
+    *out = nullptr;
+    if (nlevels < 0 || pool_rows < 0 || (nlevels > 0 && (!d_pool || !gates || !level_counts)))
+        return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    std::unique_ptr<tfhe_hip_netlist, void (*)(tfhe_hip_netlist *)> nl(new tfhe_hip_netlist, tfhe_hip_netlist_destroy);
+    nl->c = c;
+    nl->d_pool = d_pool;
+    std::vector<BrJob> br;
+    std::vector<KsJob> ks;
+    std::vector<int32_t> lin;
+    size_t ext_b = 0, abart_b = 0, part_b = 0;
+    const int32_t *g = gates;
+    for (int64_t l = 0; l < nlevels; l++) {
+        if (level_counts[l] < 0) return fail(TFHE_HIP_ERR_ARG, "negative level size");
+        if (int r = expand_level(c, pool_rows, g, level_counts[l])) return r;
+        g += 5 * level_counts[l];
+        tfhe_hip_netlist::Level lv{(long long) c->h_br.size(), (long long) c->h_ks.size(), (long long) c->h_lin.size() / 3,
+                                   br.size(), ks.size(), lin.size()};
+        br.insert(br.end(), c->h_br.begin(), c->h_br.end());
+        ks.insert(ks.end(), c->h_ks.begin(), c->h_ks.end());
+        lin.insert(lin.end(), c->h_lin.begin(), c->h_lin.end());
+        if (lv.nbr) {  // workspace of this level, as launch_ks sizes it
+            const long long Bp = (lv.nks + 32 * kKsMT - 1) / (32 * kKsMT) * (32 * kKsMT), xblocks = Bp / (32 * kKsMT);
+            int S = 1;
+            while (S < 16 && kKsYB * xblocks * S < 256) S *= 2;
+            ext_b = std::max(ext_b, (size_t) lv.nbr * kExt * sizeof(int32_t));
+            abart_b = std::max(abart_b, (size_t) ((size_t) kN * (size_t) Bp * sizeof(uint32_t)));
+            if (S > 1) part_b = std::max(part_b, (size_t) ((size_t) S * (size_t) Bp * kCt * sizeof(uint32_t)));
+        }
+        nl->levels.push_back(lv);
+    }
+    auto upload = [&](DevBuf &d, const void *src, size_t bytes) -> hipError_t {
+        if (!bytes) return hipSuccess;
+        hipError_t e = d.reserve(bytes);
+        return e == hipSuccess ? hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice) : e;
+    };
+    HIPCHK(upload(nl->jobs_br, br.data(), br.size() * sizeof(BrJob)));
+    HIPCHK(upload(nl->jobs_ks, ks.data(), ks.size() * sizeof(KsJob)));
+    HIPCHK(upload(nl->jobs_lin, lin.data(), lin.size() * sizeof(int32_t)));
+    if (ext_b) HIPCHK(nl->ext.reserve(ext_b));
+    if (abart_b) HIPCHK(nl->abart.reserve(abart_b));
+    if (part_b) HIPCHK(nl->ks_part.reserve(part_b));
+    // record the launches once; if this runtime cannot capture them, tfhe_hip_netlist_run enqueues them one by one
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!nl->levels.empty() && hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+        const int r = netlist_enqueue(nl.get());
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (r == TFHE_HIP_OK && e == hipSuccess && graph &&
+            hipGraphInstantiate(&nl->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            nl->graph = graph;
+        } else {
+            if (graph) (void) hipGraphDestroy(graph);
+            nl->exec = nullptr;
+            (void) hipGetLastError();
+        }
+    }
+    *out = nl.release();
+    return TFHE_HIP_OK;
+}
+
+int tfhe_hip_netlist_run(tfhe_hip_netlist *nl) {
+    if (!nl || !nl->c) return fail(TFHE_HIP_ERR_ARG, "null netlist");
+    if (int r = check_ctx(nl->c, true)) return r;
+    nl->c->ev_br = nl->c->ev_ks = false;
+    if (nl->levels.empty()) return TFHE_HIP_OK;
+    if (nl->exec) {
+        HIPCHK(hipGraphLaunch(nl->exec, nl->c->stream));
+        return TFHE_HIP_OK;
+    }
+    return netlist_enqueue(nl);
+}
+
+int tfhe_hip_netlist_is_graph(const tfhe_hip_netlist *nl) { return nl && nl->exec ? 1 : 0; }
 
 // device-memory helpers so that C callers of the *_dev entry points need no HIP of their own
 int tfhe_hip_dev_alloc(tfhe_hip_ctx *c, size_t bytes, void **out) {

@@ -63,7 +63,8 @@ EXPORTS = [
     "tfhe_hip_dev_alloc", "tfhe_hip_dev_free", "tfhe_hip_copy_to_dev", "tfhe_hip_copy_from_dev",
     "tfhe_hip_negacyclic_mul2048_batch", "tfhe_hip_negacyclic_mul2048_batch_dev",
     "tfhe_hip_encrypt_batch", "tfhe_hip_encrypt_batch_dev", "tfhe_hip_phase_batch", "tfhe_hip_keygen_bk",
-    "tfhe_hip_param_set",
+    "tfhe_hip_param_set", "tfhe_hip_netlist_create", "tfhe_hip_netlist_run", "tfhe_hip_netlist_is_graph",
+    "tfhe_hip_netlist_destroy",
 ]
 
 
@@ -82,6 +83,10 @@ def load_library(params=PARAMS):
         lib.tfhe_hip_last_error.restype = ctypes.c_char_p
         lib.tfhe_hip_stream.restype = ctypes.c_void_p
         lib.tfhe_hip_param_set.restype = None
+        lib.tfhe_hip_netlist_destroy.restype = None
+        lib.tfhe_hip_netlist_destroy.argtypes = [ctypes.c_void_p]
+        lib.tfhe_hip_netlist_run.argtypes = [ctypes.c_void_p]
+        lib.tfhe_hip_netlist_is_graph.argtypes = [ctypes.c_void_p]
         got = (ctypes.c_int32 * 8)()
         lib.tfhe_hip_param_set(got)
         want = [params.lam, params.n, params.N, params.k, params.l, params.Bgbit, params.ks_t, params.ks_basebit]
@@ -102,6 +107,42 @@ def _i32(arr, shape_tail):
     if a.ndim < 1 or tuple(a.shape[-len(shape_tail):]) != tuple(shape_tail):
         raise ValueError("expected trailing shape %r, got %r" % (shape_tail, a.shape))
     return a.reshape((-1,) + tuple(shape_tail))
+
+
+class CompiledNetlist:
+    """tfhe_hip_netlist: every level validated and resident on the device, replayed as one hipGraph"""
+
+    def __init__(self, engine, pool, pool_rows, levels):
+        self.engine, self.lib = engine, engine.lib
+        arrs = [np.ascontiguousarray(lv, dtype=np.int32).reshape(-1, 5) for lv in levels]
+        gates = np.concatenate(arrs) if arrs else np.zeros((0, 5), np.int32)
+        counts = np.array([a.shape[0] for a in arrs], np.int64)
+        self.n_bootstrapped = int((gates[:, 0] <= int(Gate.MUX)).sum())
+        h = ctypes.c_void_p()
+        engine._chk(self.lib.tfhe_hip_netlist_create(engine.ctx, ctypes.byref(h), engine._dptr(pool),
+                                                     ctypes.c_int64(pool_rows), _p(gates), _p(counts),
+                                                     ctypes.c_int64(len(arrs))), "netlist_create")
+        self.handle = h
+
+    @property
+    def is_graph(self):
+        return bool(self.lib.tfhe_hip_netlist_is_graph(self.handle))
+
+    def run(self, sync=True):
+        self.engine._chk(self.lib.tfhe_hip_netlist_run(self.handle), "netlist_run")
+        if sync:
+            self.engine.sync()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.tfhe_hip_netlist_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Engine:
@@ -211,6 +252,10 @@ class Engine:
         g = np.ascontiguousarray(gates, dtype=np.int32).reshape(-1, 5)
         self._chk(self.lib.tfhe_hip_gate_level_dev(self.ctx, self._dptr(pool), ctypes.c_int64(pool_rows), _p(g),
                                                    ctypes.c_int64(g.shape[0])), "gate_level_dev")
+
+    def netlist_create(self, pool, pool_rows, levels):
+        """compile a levelized circuit (list of int32[count][5] arrays) over a device-resident pool; -> CompiledNetlist"""
+        return CompiledNetlist(self, pool, pool_rows, levels)
 
     # device memory without torch (C callers use the same four functions)
     def dev_alloc(self, nbytes):
