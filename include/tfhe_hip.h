@@ -204,11 +204,17 @@ int tfhe_hip_encrypt_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, uint64_t seed,
 /* tfhe_createLweBootstrappingKey (lwe-bootstrapping-functions.cpp:185-217) on the GPU: draws bk[i] = TGSW(s_i) for
  * the given secret keys (host int32[n], int32[N], bits 0/1) with the portable generator (stream 0x10000 + i of `seed`,
  * as tfhe_client_keygen), transforms it and installs it with the keyswitch key `ks` (host, layout of
- * tfhe_hip_load_keys_coef; its 24,576 short samples come from one sequential stream and take 30 ms on one CPU core,
- * so they stay with the client library).  bk_coef_out (host int32[n][6][2][N], may be NULL) receives the coefficient
- * form, equal to tfhe_client_keygen's bit for bit.  The secret keys are wiped from device memory before returning. */
+ * tfhe_hip_load_keys_coef; NULL keeps the keyswitch key already on the device, see tfhe_hip_keygen_cloud).
+ * bk_coef_out (host int32[n][2l][2][N], may be NULL) receives the coefficient form, equal to tfhe_client_keygen's bit
+ * for bit.  The secret keys are wiped from device memory before returning. */
 int tfhe_hip_keygen_bk(tfhe_hip_ctx *ctx, uint64_t seed, const int32_t *lwe_key, const int32_t *tlwe_key,
                        const int32_t *ks, int32_t *bk_coef_out);
+/* the whole cloud keyset on the GPU: tfhe_hip_keygen_bk plus lweCreateKeySwitchKey (lwe-keyswitch-functions.cpp:163-215),
+ * both bit-identical to tfhe_client_keygen for the same seed and secret keys.  The client draws the 24,576 keyswitch
+ * samples from one sequential stream; each GPU thread jumps to its sample's position with precomputed powers of the
+ * generator's GF(2) transition matrix.  bk_coef_out / ks_out (host, layouts of tfhe_hip_load_keys_coef) may be NULL. */
+int tfhe_hip_keygen_cloud(tfhe_hip_ctx *ctx, uint64_t seed, const int32_t *lwe_key, const int32_t *tlwe_key,
+                          int32_t *bk_coef_out, int32_t *ks_out);
 int tfhe_hip_phase_batch(tfhe_hip_ctx *ctx, int32_t *phases, const int32_t *lwe_key, const int32_t *samples,
                          int64_t count);
 

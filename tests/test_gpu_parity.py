@@ -338,3 +338,30 @@ def test_batch_sizes_around_the_launch_shape_thresholds(count, engine, client, k
     pick = np.array([0, 255, 256, count // 2, count - 2, count - 1])
     want = oracle.gate_batch(okeys, Gate.ANDNY, a[pick], b[pick], None, nthreads=6)
     assert np.array_equal(out[pick], want)
+
+
+@pytest.mark.gpu
+def test_whole_cloud_keyset_generated_on_the_gpu(client, keys, engine):
+    """SURVEY 8(f) N3 completed: lweCreateKeySwitchKey (lwe-keyswitch-functions.cpp:163-215) on the GPU as well.  The
+    client draws the 24,576 keyswitch samples from one sequential xoshiro256** stream; the kernel's threads jump to
+    their positions with powers of the generator's GF(2) transition matrix.  Both keys equal the client's bit for bit,
+    and a context keyed this way produces the same ciphertexts."""
+    import time
+    from tfhe_amd import Engine
+    e2 = Engine(0)
+    try:
+        t0 = time.perf_counter()
+        bk, ks = e2.keygen_cloud(42, keys.lwe_key, keys.tlwe_key, want_keys=True)
+        dt = time.perf_counter() - t0
+        assert np.array_equal(ks, np.asarray(keys.ks).reshape(ks.shape))
+        assert np.array_equal(bk, np.asarray(keys.bk_coef).reshape(bk.shape))
+        bits = np.random.default_rng(4).integers(0, 2, (2, 40)).astype(np.uint8)
+        a, b = client.encrypt(keys, bits[0], seed=33), client.encrypt(keys, bits[1], seed=34)
+        assert np.array_equal(e2.gate_batch(Gate.OR, a, b), engine.gate_batch(Gate.OR, a, b))
+        t0 = time.perf_counter()
+        e2.keygen_cloud(7, keys.lwe_key, keys.tlwe_key)
+        dt2 = time.perf_counter() - t0
+        assert np.array_equal(client.decrypt(keys, e2.gate_batch(Gate.OR, a, b))[0], bits[0] | bits[1])
+        print("keygen_cloud %.3f s with host copies (first call builds the jump matrices), %.3f s without" % (dt, dt2))
+    finally:
+        e2.close()

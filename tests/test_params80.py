@@ -160,6 +160,10 @@ def test_client_side_kernels(engine80, client80, keys80):
         coef = e2.keygen_bk(42, keys80.lwe_key, keys80.tlwe_key, keys80.ks, want_coef=True)
         assert np.array_equal(coef, keys80.bk_coef)
         assert np.array_equal(e2.get_bkfft().view(np.int64), engine80.get_bkfft().view(np.int64))
+        bk, ks = e2.keygen_cloud(42, keys80.lwe_key, keys80.tlwe_key, want_keys=True)   # keyswitch key as well
+        assert np.array_equal(ks, keys80.ks) and np.array_equal(bk, keys80.bk_coef)
+        a, b = want[:50], want[50:100]
+        assert np.array_equal(e2.gate_batch(Gate.NOR, a, b), engine80.gate_batch(Gate.NOR, a, b))
     finally:
         e2.close()
 

@@ -1336,6 +1336,52 @@ __global__ __launch_bounds__(256) void k_client_bk_mask(const int32_t *__restric
     for (int u = 0; u < 4; u++) b[x + 256 * u] = (int32_t) acc[u];
 }
 
+// keyswitch-key generation (lweCreateKeySwitchKey, lwe-keyswitch-functions.cpp:163-215: ks[i][j][h] = LWE_n encryption
+// of h * s'_i / base^(j+1), h = 0 the trivial zero sample), bit-identical to tfhe_client_keygen, which draws all
+// 24,576 samples from ONE xoshiro256** stream, 636 draws each.  The generator's state transition is linear over GF(2),
+// so thread s reaches its starting state by applying the precomputed 256 x 256 bit matrices T^(636 * 2^k) for the
+// set bits k of s (jump[k][row][word]; lane-uniform reads), then draws its sample as the CPU does.
+constexpr int kKsDraws = 6 + kLwe;  // noise (Irwin-Hall: 6 words) + mask
+constexpr int kKsJumpBits = 15;     // N * t * (base - 1) = 24,576 samples < 2^15
+__global__ __launch_bounds__(64) void k_client_ks_draw(ClientRng start, const uint64_t *__restrict__ jump,
+                                                       const int32_t *__restrict__ lwe_key,
+                                                       const int32_t *__restrict__ tlwe_key, int32_t *__restrict__ ks) {
+    __shared__ int32_t tile[64][65];
+    const int s0 = blockIdx.x * 64, s = s0 + threadIdx.x;  // sample index = (i * t + j) * 3 + (h - 1); grid covers all
+    ClientRng r = start;
+    for (int k = 0; k < kKsJumpBits; k++) {
+        if (!((s >> k) & 1)) continue;
+        const uint64_t *m = jump + (size_t) k * 256 * 4;
+        uint64_t out[4] = {0, 0, 0, 0};
+        for (int row = 0; row < 256; row++) {
+            const uint64_t x = (m[row * 4] & r.s[0]) ^ (m[row * 4 + 1] & r.s[1]) ^ (m[row * 4 + 2] & r.s[2]) ^
+                               (m[row * 4 + 3] & r.s[3]);
+            out[row >> 6] |= (uint64_t) (__popcll(x) & 1) << (row & 63);
+        }
+        for (int w = 0; w < 4; w++) r.s[w] = out[w];
+    }
+    const int ij = s / 3, h = s % 3 + 1, i = ij / kKsT, j = ij % kKsT;
+    uint32_t b = (uint32_t) (tlwe_key[i] * h) << (32 - (j + 1) * kKsBasebit);
+    b += (uint32_t) crng_gauss(r, kKsNoiseM);
+    // rows of the host layout [N][t][4][n+1]; the mask words of 64 samples pass through LDS for coalesced stores
+    for (int q0 = 0; q0 < kLwe; q0 += 64) {
+        const int nq = kLwe - q0 < 64 ? kLwe - q0 : 64;
+        for (int q = 0; q < nq; q++) {
+            const int32_t a = (int32_t) (uint32_t) (crng_next(r) >> 32);
+            tile[threadIdx.x][q] = a;
+            b += (uint32_t) a * (uint32_t) lwe_key[q0 + q];
+        }
+        __syncthreads();
+        for (int t = 0; t < 64; t++) {
+            const int st = s0 + t;
+            const size_t rowoff = ((size_t) (st / 3) * 4 + (st % 3 + 1)) * kCt;
+            if ((int) threadIdx.x < nq) ks[rowoff + q0 + threadIdx.x] = tile[t][threadIdx.x];
+        }
+        __syncthreads();
+    }
+    ks[((size_t) ij * 4 + h) * kCt + kLwe] = (int32_t) b;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -1562,9 +1608,14 @@ int check_ctx(tfhe_hip_ctx *c, bool need_keys) {
     return TFHE_HIP_OK;
 }
 
+// the keyswitch key in the host layout [N][t][4][n+1] sits in c->misc: pack it into the two device layouts
+int pack_ks_from_misc(tfhe_hip_ctx *c);
 int upload_ks(tfhe_hip_ctx *c, const int32_t *ks) {
     HIPCHK(c->misc.reserve(kKsHostElems * sizeof(int32_t)));
     HIPCHK(hipMemcpyAsync(c->misc.p, ks, kKsHostElems * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    return pack_ks_from_misc(c);
+}
+int pack_ks_from_misc(tfhe_hip_ctx *c) {
     if (!c->ks) HIPCHK(hipMalloc((void **) &c->ks, kKsDevBytes));
     const long long rows = (long long) kN * kKsT * 3;
     hipLaunchKernelGGL(k_ks_pack, dim3((unsigned) rows), dim3(256), 0, c->stream, c->ks, (const int32_t *) c->misc.p, rows);
@@ -1655,8 +1706,10 @@ static int keys_from_coef_in_misc(tfhe_hip_ctx *c, const int32_t *ks) {
                        c->bk, (const c64 *) c->tw, c->ka, npoly);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));  // misc is reused by upload_ks
-    if (int r = upload_ks(c, ks)) return r;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (ks) {  // null: the keyswitch key has been packed on the device already (tfhe_hip_keygen_cloud)
+        if (int r = upload_ks(c, ks)) return r;
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     c->misc.release();
     c->have_keys = true;
     return TFHE_HIP_OK;
@@ -1674,10 +1727,96 @@ int tfhe_hip_load_keys_coef(tfhe_hip_ctx *c, const int32_t *bk_coef, const int32
     return keys_from_coef_in_misc(c, ks);
 }
 
+}  // extern "C"
+namespace {
+// xoshiro256** state transition as a 256 x 256 matrix over GF(2), rows as 4 words: (M v)_i = parity(M[i] & v)
+struct BitMat {
+    uint64_t r[256][4];
+};
+void xoshiro_step(uint64_t s[4]) {
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = (s[3] << 45) | (s[3] >> 19);
+}
+void bitmat_mul(BitMat &out, const BitMat &a, const BitMat &b) {  // out = a * b: row i = XOR of the rows k of b with a[i][k] set
+    for (int i = 0; i < 256; i++) {
+        uint64_t acc[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 256; k++)
+            if ((a.r[i][k >> 6] >> (k & 63)) & 1)
+                for (int w = 0; w < 4; w++) acc[w] ^= b.r[k][w];
+        for (int w = 0; w < 4; w++) out.r[i][w] = acc[w];
+    }
+}
+// jump[k] = T^(draws * 2^k), k < nbits
+void build_jump_matrices(std::vector<BitMat> &jump, int draws, int nbits) {
+    auto T = std::make_unique<BitMat>(), acc = std::make_unique<BitMat>(), tmp = std::make_unique<BitMat>();
+    std::memset(T.get(), 0, sizeof(BitMat));
+    for (int bcol = 0; bcol < 256; bcol++) {  // column bcol = image of the basis vector e_bcol
+        uint64_t s[4] = {0, 0, 0, 0};
+        s[bcol >> 6] = 1ull << (bcol & 63);
+        xoshiro_step(s);
+        for (int i = 0; i < 256; i++)
+            if ((s[i >> 6] >> (i & 63)) & 1) T->r[i][bcol >> 6] |= 1ull << (bcol & 63);
+    }
+    std::memset(acc.get(), 0, sizeof(BitMat));
+    for (int i = 0; i < 256; i++) acc->r[i][i >> 6] = 1ull << (i & 63);  // identity
+    auto base = std::make_unique<BitMat>(*T);
+    for (int e = draws; e; e >>= 1) {  // acc = T^draws
+        if (e & 1) { bitmat_mul(*tmp, *base, *acc); std::swap(acc, tmp); }
+        bitmat_mul(*tmp, *base, *base);
+        std::swap(base, tmp);
+    }
+    jump.resize(nbits);
+    jump[0] = *acc;
+    for (int k = 1; k < nbits; k++) bitmat_mul(jump[k], jump[k - 1], jump[k - 1]);
+}
+uint64_t host_splitmix(uint64_t &x) {
+    uint64_t z = (x += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+}  // namespace
+extern "C" {
+
+int tfhe_hip_keygen_cloud(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key, const int32_t *tlwe_key,
+                          int32_t *bk_coef_out, int32_t *ks_out) {
+    if (int r = check_ctx(c, false)) return r;
+    if (!lwe_key || !tlwe_key) return fail(TFHE_HIP_ERR_ARG, "null key pointer");
+    c->have_keys = false;
+    static std::vector<BitMat> jump;  // depends on the parameter set only
+    static std::once_flag once;
+    std::call_once(once, [] { build_jump_matrices(jump, kKsDraws, kKsJumpBits); });
+    ClientRng start;  // stream 3 of the seed: tfhe_client_keygen (client_keys.c)
+    uint64_t x = seed ^ (3ULL * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL);
+    for (int i = 0; i < 4; i++) start.s[i] = host_splitmix(x);
+    const size_t jump_bytes = (size_t) kKsJumpBits * sizeof(BitMat);
+    HIPCHK(c->misc.reserve(kKsHostElems * sizeof(int32_t)));
+    HIPCHK(c->abart.reserve(jump_bytes + (kLwe + kN) * sizeof(int32_t)));
+    uint64_t *d_jump = (uint64_t *) c->abart.p;
+    int32_t *d_lwe = (int32_t *) ((unsigned char *) c->abart.p + jump_bytes), *d_tlwe = d_lwe + kLwe;
+    HIPCHK(hipMemcpyAsync(d_jump, jump.data(), jump_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_lwe, lwe_key, kLwe * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_tlwe, tlwe_key, kN * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->misc.p, 0, kKsHostElems * sizeof(int32_t), c->stream));  // the h = 0 rows
+    static_assert(kN * kKsT * 3 % 64 == 0, "whole workgroups of samples");
+    hipLaunchKernelGGL(k_client_ks_draw, dim3(kN * kKsT * 3 / 64), dim3(64), 0, c->stream, start, (const uint64_t *) d_jump,
+                       (const int32_t *) d_lwe, (const int32_t *) d_tlwe, (int32_t *) c->misc.p);
+    HIPCHK(hipGetLastError());
+    if (ks_out) HIPCHK(hipMemcpyAsync(ks_out, c->misc.p, kKsHostElems * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    int r = pack_ks_from_misc(c);
+    const hipError_t w1 = hipMemsetAsync((unsigned char *) c->abart.p + jump_bytes, 0, (kLwe + kN) * sizeof(int32_t), c->stream);
+    const hipError_t w2 = hipStreamSynchronize(c->stream);
+    if (r == TFHE_HIP_OK && (w1 != hipSuccess || w2 != hipSuccess))
+        r = fail(TFHE_HIP_ERR_HIP, "could not wipe the secret keys from device memory");
+    if (r) return r;
+    return tfhe_hip_keygen_bk(c, seed, lwe_key, tlwe_key, nullptr, bk_coef_out);
+}
+
 int tfhe_hip_keygen_bk(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key, const int32_t *tlwe_key, const int32_t *ks,
                        int32_t *bk_coef_out) {
     if (int r = check_ctx(c, false)) return r;
-    if (!lwe_key || !tlwe_key || !ks) return fail(TFHE_HIP_ERR_ARG, "null key pointer");
+    if (!lwe_key || !tlwe_key) return fail(TFHE_HIP_ERR_ARG, "null key pointer");
+    if (!ks && !c->kl) return fail(TFHE_HIP_ERR_ARG, "no keyswitch key given and none on the device");
     c->have_keys = false;
     const size_t coef_bytes = (size_t) kLwe * kKpl * 2 * kN * sizeof(int32_t);
     if (!c->bk) HIPCHK(hipMalloc((void **) &c->bk, kBkBytes));

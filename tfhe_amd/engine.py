@@ -64,7 +64,7 @@ EXPORTS = [
     "tfhe_hip_negacyclic_mul2048_batch", "tfhe_hip_negacyclic_mul2048_batch_dev",
     "tfhe_hip_encrypt_batch", "tfhe_hip_encrypt_batch_dev", "tfhe_hip_phase_batch", "tfhe_hip_keygen_bk",
     "tfhe_hip_param_set", "tfhe_hip_netlist_create", "tfhe_hip_netlist_run", "tfhe_hip_netlist_is_graph",
-    "tfhe_hip_netlist_destroy",
+    "tfhe_hip_netlist_destroy", "tfhe_hip_keygen_cloud",
 ]
 
 
@@ -313,6 +313,17 @@ class Engine:
         self._chk(self.lib.tfhe_hip_keygen_bk(self.ctx, ctypes.c_uint64(seed), _p(lk), _p(tk), _p(ks),
                                               _p(out) if want_coef else None), "keygen_bk")
         return out
+
+    def keygen_cloud(self, seed, lwe_key, tlwe_key, want_keys=False):
+        """draw both cloud keys on the device from the secret keys and install them; returns (bk_coef, ks) if asked"""
+        P = self.params
+        lk = _i32(lwe_key, (P.n,)).reshape(-1)
+        tk = _i32(tlwe_key, (P.N,)).reshape(-1)
+        bk = np.empty((P.n, P.kpl, 2, P.N), np.int32) if want_keys else None
+        ks = np.empty((P.N, P.ks_t, P.ks_base, P.n + 1), np.int32) if want_keys else None
+        self._chk(self.lib.tfhe_hip_keygen_cloud(self.ctx, ctypes.c_uint64(seed), _p(lk), _p(tk), _p(bk), _p(ks)),
+                  "keygen_cloud")
+        return (bk, ks) if want_keys else None
 
     def phase_batch(self, lwe_key, samples):
         key = _i32(lwe_key, (self.params.n,)).reshape(-1)
