@@ -4,10 +4,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <memory>
 #include <mutex>
-#include <thread>
 #include <vector>
 #include "../../include/tfhe_hip_compat.h"
+#include "internal.h"
 
 namespace {
 constexpr int kn = TFHE_HIP_n, kN = TFHE_HIP_N, kKpl = TFHE_HIP_KPL, kT = TFHE_HIP_KS_T, kBase = TFHE_HIP_KS_BASE;
@@ -56,14 +57,6 @@ tfhe_hip_ctx *default_ctx_locked() {
     return g_ctx;
 }
 
-void pack(std::vector<int32_t> &dst, const LweSample *s, int32_t count) {
-    dst.resize((size_t) count * (kn + 1));
-    for (int32_t i = 0; i < count; i++) {
-        std::memcpy(dst.data() + (size_t) i * (kn + 1), s[i].a, sizeof(int32_t) * kn);
-        dst[(size_t) i * (kn + 1) + kn] = s[i].b;
-    }
-}
-
 void boots_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b, const LweSample *c, int32_t count,
                  const TFheGateBootstrappingCloudKeySet *bk) {
     std::lock_guard<std::mutex> lock(g_mu);
@@ -87,52 +80,58 @@ int tfhe_hip_load_cloud_keyset(tfhe_hip_ctx *ctx, const TFheGateBootstrappingClo
     return load_keys(ctx, k->bkFFT, k->ks);
 }
 
-// The pointer-rich LweSample arrays (each sample owns a separately allocated a[630], lwesamples.cpp:5-10) are packed
-// into flat buffers chunk by chunk; a helper thread scatters the results of chunk k-1 and packs chunk k+1 while the GPU
-// works on chunk k, so that the packing (165 MB of small copies per 16,384 NAND gates) hides behind the kernels.
+// The pointer-rich LweSample arrays (each sample owns a separately allocated a[n], lwesamples.cpp:5-10) are packed
+// into flat buffers chunk by chunk through the hooks of the host-buffer pipeline (internal.h): the calling thread packs
+// chunk k+1 and scatters the results of chunk k-1 while the GPU works on chunk k, so that the packing (165 MB of small
+// copies per 16,384 NAND gates) hides behind the kernels.
 int tfhe_hip_gate_batch_samples(tfhe_hip_ctx *ctx, int gate, LweSample *result, const LweSample *a,
                                 const LweSample *b, const LweSample *c, int32_t count) {
     if (!ctx || count < 0 || (count > 0 && !result)) return TFHE_HIP_ERR_ARG;
     if (count == 0) return TFHE_HIP_OK;
-    constexpr int32_t kChunk = 4096;  // two full rounds of the blind-rotation kernel on one GPU
-    struct Chunk {
-        std::vector<int32_t> fa, fb, fc, fo;
-        int32_t off = 0, n = 0;
-    } ch[2];
-    auto pack_chunk = [&](Chunk &k, int32_t off) {
-        k.off = off;
-        k.n = std::min(kChunk, count - off);
-        if (a) pack(k.fa, a + off, k.n);
-        if (b) pack(k.fb, b + off, k.n);
-        if (c) pack(k.fc, c + off, k.n);
-        k.fo.resize((size_t) k.n * (kn + 1));
+    // flat staging buffers, kept per thread and only ever grown: a fresh 165 MB per call would cost more in page
+    // faults and zero-filling than the packing itself
+    struct Staging {
+        std::unique_ptr<int32_t[]> p;
+        size_t cap = 0;
+        int32_t *get(size_t elems) {
+            if (elems > cap) {
+                p.reset(new int32_t[elems]);
+                cap = elems;
+            }
+            return p.get();
+        }
     };
-    auto scatter_chunk = [&](const Chunk &k) {
-        for (int32_t i = 0; i < k.n; i++) {
-            LweSample &r = result[k.off + i];
-            std::memcpy(r.a, k.fo.data() + (size_t) i * (kn + 1), sizeof(int32_t) * kn);
-            r.b = k.fo[(size_t) i * (kn + 1) + kn];
+    thread_local Staging st_a, st_b, st_c, st_o;
+    struct Job {
+        LweSample *result;
+        const LweSample *a, *b, *c;
+        int32_t *fa, *fb, *fc, *fo;
+    };
+    const size_t elems = (size_t) count * (kn + 1);
+    Job job{result, a, b, c, a ? st_a.get(elems) : nullptr, b ? st_b.get(elems) : nullptr, c ? st_c.get(elems) : nullptr,
+            st_o.get(elems)};
+    static const auto fill = [](void *user, long long off, long long n) {
+        Job &j = *static_cast<Job *>(user);
+        auto pr = [&](int32_t *dst, const LweSample *s) {
+            for (long long i = off; i < off + n; i++) {
+                std::memcpy(dst + (size_t) i * (kn + 1), s[i].a, sizeof(int32_t) * kn);
+                dst[(size_t) i * (kn + 1) + kn] = s[i].b;
+            }
+        };
+        if (j.a) pr(j.fa, j.a);
+        if (j.b) pr(j.fb, j.b);
+        if (j.c) pr(j.fc, j.c);
+    };
+    static const auto drain = [](void *user, long long off, long long n) {
+        Job &j = *static_cast<Job *>(user);
+        for (long long i = off; i < off + n; i++) {
+            LweSample &r = j.result[i];
+            std::memcpy(r.a, j.fo + (size_t) i * (kn + 1), sizeof(int32_t) * kn);
+            r.b = j.fo[(size_t) i * (kn + 1) + kn];
             r.current_variance = 0.;   // bookkeeping only in the reference (SURVEY 8(a) note 2)
         }
     };
-    const int32_t nchunks = (count + kChunk - 1) / kChunk;
-    pack_chunk(ch[0], 0);
-    int rc = TFHE_HIP_OK;
-    for (int32_t k = 0; k < nchunks && rc == TFHE_HIP_OK; k++) {
-        Chunk &cur = ch[k & 1], &other = ch[(k + 1) & 1];
-        std::thread helper;
-        if (nchunks > 1)
-            helper = std::thread([&, k] {
-                if (k > 0) scatter_chunk(other);                       // results of chunk k-1
-                if (k + 1 < nchunks) pack_chunk(other, (k + 1) * kChunk);
-            });
-        rc = tfhe_hip_gate_batch(ctx, gate, cur.fo.data(), a ? cur.fa.data() : nullptr, b ? cur.fb.data() : nullptr,
-                                 c ? cur.fc.data() : nullptr, cur.n);
-        if (helper.joinable()) helper.join();
-    }
-    if (rc != TFHE_HIP_OK) return rc;
-    scatter_chunk(ch[(nchunks - 1) & 1]);
-    return TFHE_HIP_OK;
+    return tfhe_hip_internal_gate_batch(ctx, gate, job.fo, job.fa, job.fb, job.fc, count, +fill, +drain, &job);
 }
 
 #define BINARY(NAME, ID)                                                                                      \

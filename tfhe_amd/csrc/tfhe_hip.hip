@@ -1989,12 +1989,22 @@ static int d2h(tfhe_hip_ctx *c, void *dst, const void *src, size_t bytes) {
 // second stream while the kernels of chunk k run, so that PCIe time hides behind the blind rotation.
 int tfhe_hip_gate_batch(tfhe_hip_ctx *c, int gate, int32_t *out, const int32_t *a, const int32_t *b, const int32_t *cc,
                         int64_t count) {
+    return tfhe_hip_internal_gate_batch(c, gate, out, a, b, cc, count, nullptr, nullptr, nullptr);
+}
+}  // extern "C"
+
+// Host buffers: chunks of 4,096 gates (two full rounds of the blind-rotation kernel; the first chunk is one round,
+// so that less copying - and, with hooks, packing - stands before the first kernel).  The copies of chunk k+1 and
+// k-1 run on a second stream, and the hooks on the calling thread, while the kernels of chunk k run.
+int tfhe_hip_internal_gate_batch(tfhe_hip_ctx *c, int gate, int *out, const int *a, const int *b, const int *cc,
+                                 long long count, tfhe_hip_chunk_hook fill, tfhe_hip_chunk_hook drain, void *user) {
     if (int r = check_ctx(c, false)) return r;
     if (count < 0 || (count > 0 && !out)) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
     if (count == 0) return TFHE_HIP_OK;
     const size_t bytes = (size_t) count * kCt * sizeof(int32_t);
-    constexpr int64_t kChunk = 4096;  // two full rounds of the blind-rotation kernel
+    constexpr int64_t kChunk = 4096, kFirst = 2048;
     if (count <= kChunk) {
+        if (fill) fill(user, 0, count);
         if (a) if (int r = h2d(c, c->in_a, a, bytes)) return r;
         if (b) if (int r = h2d(c, c->in_b, b, bytes)) return r;
         if (cc) if (int r = h2d(c, c->in_c, cc, bytes)) return r;
@@ -2003,38 +2013,51 @@ int tfhe_hip_gate_batch(tfhe_hip_ctx *c, int gate, int32_t *out, const int32_t *
                                             b ? (const int32_t *) c->in_b.p : nullptr,
                                             cc ? (const int32_t *) c->in_c.p : nullptr, count))
             return r;
-        return d2h(c, out, c->outb.p, bytes);
+        if (int r = d2h(c, out, c->outb.p, bytes)) return r;
+        if (drain) drain(user, 0, count);
+        return TFHE_HIP_OK;
     }
     if (a) HIPCHK(c->in_a.reserve(bytes));
     if (b) HIPCHK(c->in_b.reserve(bytes));
     if (cc) HIPCHK(c->in_c.reserve(bytes));
     HIPCHK(c->outb.reserve(bytes));
-    const int64_t nchunks = (count + kChunk - 1) / kChunk;
-    while ((int64_t) c->chunk_ev.size() < 2 * nchunks) {
+    const int64_t nchunks = 1 + (count - kFirst + kChunk - 1) / kChunk;
+    while ((int64_t) c->chunk_ev.size() < 3 * nchunks) {
         hipEvent_t ev;
         HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         c->chunk_ev.push_back(ev);
     }
     auto span = [&](int64_t k, int64_t &off, int64_t &n) {
-        off = k * kChunk;
-        n = count - off < kChunk ? count - off : kChunk;
+        off = k == 0 ? 0 : kFirst + (k - 1) * kChunk;
+        const int64_t want = k == 0 ? kFirst : kChunk;
+        n = count - off < want ? count - off : want;
     };
-    auto copy_in = [&](int64_t k) -> int {
+    auto copy_in = [&](int64_t k) -> int {  // events of chunk k: [3k] inputs on the device, [3k+1] kernels done, [3k+2] output on the host
         int64_t off, n;
         span(k, off, n);
+        if (fill) fill(user, off, n);
         const size_t o = (size_t) off * kCt, nb = (size_t) n * kCt * sizeof(int32_t);
         if (a) HIPCHK(hipMemcpyAsync((int32_t *) c->in_a.p + o, a + o, nb, hipMemcpyHostToDevice, c->copy_stream));
         if (b) HIPCHK(hipMemcpyAsync((int32_t *) c->in_b.p + o, b + o, nb, hipMemcpyHostToDevice, c->copy_stream));
         if (cc) HIPCHK(hipMemcpyAsync((int32_t *) c->in_c.p + o, cc + o, nb, hipMemcpyHostToDevice, c->copy_stream));
-        HIPCHK(hipEventRecord(c->chunk_ev[2 * k], c->copy_stream));
+        HIPCHK(hipEventRecord(c->chunk_ev[3 * k], c->copy_stream));
         return TFHE_HIP_OK;
     };
     auto copy_out = [&](int64_t k) -> int {
         int64_t off, n;
         span(k, off, n);
         const size_t o = (size_t) off * kCt, nb = (size_t) n * kCt * sizeof(int32_t);
-        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->chunk_ev[2 * k + 1], 0));
+        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->chunk_ev[3 * k + 1], 0));
         HIPCHK(hipMemcpyAsync(out + o, (int32_t *) c->outb.p + o, nb, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(hipEventRecord(c->chunk_ev[3 * k + 2], c->copy_stream));
+        return TFHE_HIP_OK;
+    };
+    auto drain_chunk = [&](int64_t k) -> int {
+        if (!drain) return TFHE_HIP_OK;
+        int64_t off, n;
+        span(k, off, n);
+        HIPCHK(hipEventSynchronize(c->chunk_ev[3 * k + 2]));
+        drain(user, off, n);
         return TFHE_HIP_OK;
     };
     int rc = copy_in(0);
@@ -2042,20 +2065,24 @@ int tfhe_hip_gate_batch(tfhe_hip_ctx *c, int gate, int32_t *out, const int32_t *
         int64_t off, n;
         span(k, off, n);
         const size_t o = (size_t) off * kCt;
-        HIPCHK(hipStreamWaitEvent(c->stream, c->chunk_ev[2 * k], 0));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->chunk_ev[3 * k], 0));
         rc = tfhe_hip_gate_batch_dev(c, gate, (int32_t *) c->outb.p + o, a ? (const int32_t *) c->in_a.p + o : nullptr,
                                      b ? (const int32_t *) c->in_b.p + o : nullptr,
                                      cc ? (const int32_t *) c->in_c.p + o : nullptr, n);
         if (rc != TFHE_HIP_OK) break;
-        HIPCHK(hipEventRecord(c->chunk_ev[2 * k + 1], c->stream));
+        HIPCHK(hipEventRecord(c->chunk_ev[3 * k + 1], c->stream));
         if (k + 1 < nchunks) rc = copy_in(k + 1);
         if (rc == TFHE_HIP_OK && k > 0) rc = copy_out(k - 1);
+        if (rc == TFHE_HIP_OK && k > 0) rc = drain_chunk(k - 1);
     }
     if (rc == TFHE_HIP_OK) rc = copy_out(nchunks - 1);
     (void) hipStreamSynchronize(c->copy_stream);
     (void) hipStreamSynchronize(c->stream);
+    if (rc == TFHE_HIP_OK) rc = drain_chunk(nchunks - 1);
     return rc;
 }
+
+extern "C" {
 
 int tfhe_hip_bootstrap_batch(tfhe_hip_ctx *c, int32_t *out, const int32_t *in, int32_t mu, int64_t count, int with_ks) {
     if (int r = check_ctx(c, true)) return r;
