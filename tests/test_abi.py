@@ -62,3 +62,24 @@ def test_product_does_not_touch_the_oracle():
                 "tfhe_amd/csrc/compat_libtfhe.cpp", "tfhe_amd/wire.py", "tfhe_amd/netlist.py", "tfhe_amd/parallel.py"):
         text = open(os.path.join(ROOT, rel)).read()
         assert "liboracle" not in text and "tfhe_oracle" not in text and "oracle_lib" not in text, rel
+
+
+def _build_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "nand_batch")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "nand_batch.c"), "-L" + os.path.join(ROOT, "tfhe_amd"), "-ltfhe_hip",
+                    "-ltfhe_client", "-Wl,-rpath," + os.path.join(ROOT, "tfhe_amd"), "-o", exe], check=True)
+    return exe
+
+
+def test_plain_c_example_compiles_and_links(tmp_path):
+    """examples/nand_batch.c: a C99 host against include/tfhe_hip.h alone (no C++ in the header, every symbol resolves)"""
+    assert os.path.exists(_build_example(tmp_path))
+
+
+@pytest.mark.gpu
+def test_plain_c_example_runs(tmp_path):
+    import subprocess
+    out = subprocess.run([_build_example(tmp_path), "300"], check=True, capture_output=True, text=True, timeout=120).stdout
+    assert "300 NAND gates, 0 wrong" in out

@@ -365,3 +365,24 @@ def test_whole_cloud_keyset_generated_on_the_gpu(client, keys, engine):
         print("keygen_cloud %.3f s with host copies (first call builds the jump matrices), %.3f s without" % (dt, dt2))
     finally:
         e2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count", [4097, 6145])
+def test_host_buffer_pipeline_chunk_boundaries(count, engine, client, keys):
+    """tfhe_hip_gate_batch on host buffers: a first chunk of 2,048 gates, then chunks of 4,096, copies on a second
+    stream; the result must equal the device-resident call on the same inputs whatever the tail chunk's size (1 gate
+    for 6,145; 2,049 for 4,097)"""
+    rng = np.random.default_rng(count)
+    bits = rng.integers(0, 2, (2, count)).astype(np.uint8)
+    a, b = client.encrypt(keys, bits[0], seed=70), client.encrypt(keys, bits[1], seed=71)
+    host = engine.gate_batch(Gate.XNOR, a, b)
+    d_a, d_b, d_o = (engine.dev_alloc(a.nbytes) for _ in range(3))
+    engine.to_dev(d_a, a)
+    engine.to_dev(d_b, b)
+    engine.gate_batch_dev(Gate.XNOR, d_o, d_a, d_b, None, count=count)
+    dev = engine.from_dev(d_o, a.shape)
+    for p in (d_a, d_b, d_o):
+        engine.dev_free(p)
+    assert np.array_equal(host, dev)
+    assert np.array_equal(client.decrypt(keys, host)[0], 1 - (bits[0] ^ bits[1]))
