@@ -1,0 +1,117 @@
+"""BASELINE.json configs at their full per-GPU sizes, on the GPU through the C-ABI:
+  configs[2]  one GPU's shard of the 2^20-gate batch (131,072 gates),
+  configs[3]  the 32-bit ripple-carry adder and comparator netlists of src/test/test-addition-boot.cpp:30-115, and the
+              level-by-level sharding over ranks (two ranks on the one GPU of the test box, gloo collectives).
+Bit-exact rows against the oracle; size-independent properties (decrypt = truth table, phase margin) on everything."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tfhe_amd import Gate, PARAMS as P
+from tfhe_amd.netlist import Netlist, comparison_mux, full_adder, full_adder_mux
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config2_shard_of_131072_gates(engine, client, keys, oracle, okeys):
+    count = (1 << 20) // 8
+    rng = np.random.default_rng(2020)
+    bits = rng.integers(0, 2, (2, count)).astype(np.uint8)
+    ca, cb = client.encrypt(keys, bits[0], 1201), client.encrypt(keys, bits[1], 1202)
+    d_a, d_b, d_o = (engine.dev_alloc(ca.nbytes) for _ in range(3))
+    try:
+        engine.to_dev(d_a, ca)
+        engine.to_dev(d_b, cb)
+        engine.gate_batch_dev(Gate.NAND, d_o, d_a, d_b, None, count=count)
+        got = engine.from_dev(d_o, ca.shape)
+    finally:
+        for p in (d_a, d_b, d_o):
+            engine.dev_free(p)
+    dec, phases = client.decrypt(keys, got)
+    assert np.array_equal(dec, 1 - (bits[0] & bits[1]))
+    assert np.abs(np.abs(phases.astype(np.int64)) - (1 << 29)).max() < (1 << 28)
+    pick = np.unique(np.concatenate([np.arange(64), rng.integers(0, count, 112), np.arange(count - 16, count)]))
+    assert pick.shape[0] >= 180
+    want = oracle.gate_batch(okeys, Gate.NAND, ca[pick], cb[pick], None, nthreads=16)
+    assert np.array_equal(got[pick], want)
+
+
+@pytest.mark.parametrize("kind", ["cmp", "add", "addmux"])
+def test_config3_32bit_circuits(kind, engine, client, keys):
+    """32-bit comparison_MUX / full_adder / full_adder_MUX, W instances per level, as compiled netlists; decrypted
+    results equal the plain computation (the reference's own check, src/test/test-addition-boot.cpp:177-254)"""
+    nbits, W = 32, 24
+    nl = Netlist()
+    x, y = nl.input("x", nbits), nl.input("y", nbits)
+    nl.output("out", {"add": full_adder, "addmux": full_adder_mux, "cmp": comparison_mux}[kind](nl, x, y))
+    rng = np.random.default_rng(len(kind))
+    xs = rng.integers(0, 1 << nbits, W, dtype=np.int64)
+    ys = rng.integers(0, 1 << nbits, W, dtype=np.int64)
+    ys[:3] = xs[:3] + np.array([0, 1, -1])       # equal, just above, just below: the comparator's hard cases
+    ys = np.clip(ys, 0, (1 << nbits) - 1)
+    pool = np.zeros((W * nl.n_wires, P.n + 1), np.int32)
+    sh = np.arange(nbits)
+    base = (np.arange(W) * nl.n_wires)[:, None]
+    pool[(base + np.array(x)[None, :]).reshape(-1)] = client.encrypt(keys, ((xs[:, None] >> sh) & 1).reshape(-1), 1301)
+    pool[(base + np.array(y)[None, :]).reshape(-1)] = client.encrypt(keys, ((ys[:, None] >> sh) & 1).reshape(-1), 1302)
+    d_pool = engine.dev_alloc(pool.nbytes)
+    try:
+        engine.to_dev(d_pool, pool)
+        compiled = engine.netlist_create(d_pool, pool.shape[0], nl.level_arrays(instances=W))
+        compiled.run()
+        compiled.close()
+        res = engine.from_dev(d_pool, pool.shape)
+    finally:
+        engine.dev_free(d_pool)
+    outs = np.array(nl.outputs["out"])
+    bits, _ = client.decrypt(keys, res[(base + outs[None, :]).reshape(-1)])
+    got = (bits.reshape(W, -1).astype(np.int64) << np.arange(outs.shape[0])).sum(axis=1)
+    assert np.array_equal(got, (xs <= ys).astype(np.int64) if kind == "cmp" else xs + ys), kind
+
+
+def test_two_ranks_on_one_gpu(tmp_path, engine, client, keys):
+    """BASELINE configs[2]/[3], the N > 1 path with the GPU engine as the per-rank compute: two processes, both on GPU 0,
+    gloo collectives.  The gathered batch and both ranks' pools must equal the single-process results bit for bit."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    r0, r1 = (np.load(tmp_path / ("rank%d.npz" % k)) for k in range(2))
+    assert np.array_equal(r0["out"], r1["out"]) and np.array_equal(r0["pool"], r1["pool"])
+    # single process, same inputs (the worker's generator and seeds)
+    rng = np.random.default_rng(31)
+    count = 1537
+    bits = rng.integers(0, 2, (2, count)).astype(np.uint8)
+    ca, cb = client.encrypt(keys, bits[0], 501), client.encrypt(keys, bits[1], 502)
+    assert np.array_equal(engine.gate_batch(Gate.XOR, ca, cb), r0["out"])
+    nbits, W = 4, 9
+    nl = Netlist()
+    x, y = nl.input("x", nbits), nl.input("y", nbits)
+    nl.output("out", full_adder_mux(nl, x, y))
+    xs, ys = rng.integers(0, 1 << nbits, W), rng.integers(0, 1 << nbits, W)
+    assert np.array_equal(xs, r0["xs"]) and np.array_equal(ys, r0["ys"])
+    host = np.zeros((W * nl.n_wires, P.n + 1), np.int32)
+    for k in range(W):
+        host[k * nl.n_wires + np.array(x)] = client.encrypt(keys, ((xs[k] >> np.arange(nbits)) & 1).astype(np.uint8), 600 + k)
+        host[k * nl.n_wires + np.array(y)] = client.encrypt(keys, ((ys[k] >> np.arange(nbits)) & 1).astype(np.uint8), 700 + k)
+    d_pool = engine.dev_alloc(host.nbytes)
+    try:
+        engine.to_dev(d_pool, host)
+        nl.evaluate(lambda lv: engine.gate_level_dev(d_pool, host.shape[0], lv), instances=W)
+        single = engine.from_dev(d_pool, host.shape)
+    finally:
+        engine.dev_free(d_pool)
+    assert np.array_equal(single, r0["pool"])
+    for k in range(W):
+        b, _ = client.decrypt(keys, single[k * nl.n_wires + np.array(nl.outputs["out"])])
+        assert int(sum(int(v) << i for i, v in enumerate(b))) == int(xs[k] + ys[k])

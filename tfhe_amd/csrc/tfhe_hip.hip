@@ -1476,6 +1476,7 @@ struct tfhe_hip_ctx {
     std::vector<uint8_t> h_mark;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // br start/stop, ks start/stop
     bool ev_br = false, ev_ks = false;
+    long long fault_chunk = -1;  // test hook: fail the host pipeline at this chunk once (TFHE_HIP_TEST_FAIL_CHUNK)
     int br_waves = 0;  // 0 = by batch size; TFHE_HIP_BR_WAVES=1|4|8 forces a shape, 6 the one-workgroup-per-ciphertext kernel
 };
 
@@ -1550,27 +1551,56 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
     return TFHE_HIP_OK;
 }
 
-int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B, const KsJob *kj = nullptr) {
+// workspace of one keyswitch launch: the transposed input and, for small batches, the partial sums.  Null = the
+// context's own growable buffers; the entry point that allocates nothing brings slices of its static array.
+struct KsWork {
+    uint32_t *abart;
+    size_t abart_bytes;
+    uint32_t *part;
+    size_t part_bytes;
+};
+// split of the input coefficients over block groups for a batch of Bp (padded) ciphertexts: fill the 256 CUs
+int ks_split(long long Bp) {
+    const long long xblocks = Bp / (32 * kKsMT);
+    int S = 1;
+    while (S < 16 && kKsYB * xblocks * S < 256) S *= 2;
+    return S;
+}
+int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B, const KsJob *kj = nullptr,
+              const KsWork *ws = nullptr) {
     if (B <= 0) return TFHE_HIP_OK;
-    if (c->ks_mfma || kj) {
+    if (c->ks_mfma || kj || ws) {
         const long long Bp = (B + 32 * kKsMT - 1) / (32 * kKsMT) * (32 * kKsMT);
-        HIPCHK(c->abart.reserve((size_t) kN * Bp * sizeof(uint32_t)));
-        hipLaunchKernelGGL(k_ks_transpose, dim3((unsigned) (Bp / 32), kN / 32), dim3(256), 0, c->stream,
-                           (uint32_t *) c->abart.p, d_in, B, Bp, kj);
+        const size_t abart_bytes = (size_t) kN * Bp * sizeof(uint32_t);
+        uint32_t *abart;
+        if (ws) {
+            if (abart_bytes > ws->abart_bytes) return fail(TFHE_HIP_ERR_ARG, "keyswitch workspace too small");
+            abart = ws->abart;
+        } else {
+            HIPCHK(c->abart.reserve(abart_bytes));
+            abart = (uint32_t *) c->abart.p;
+        }
+        hipLaunchKernelGGL(k_ks_transpose, dim3((unsigned) (Bp / 32), kN / 32), dim3(256), 0, c->stream, abart, d_in, B, Bp, kj);
         const long long xblocks = Bp / (32 * kKsMT);
-        int S = 1;
-        while (S < 16 && kKsYB * xblocks * S < 256) S *= 2;   // fill the 256 CUs
+        int S = ks_split(Bp);
+        if (ws)  // a fixed workspace: as many parts as fit (any split gives the same bits: integer sums)
+            while (S > 1 && (size_t) S * Bp * kCt * sizeof(uint32_t) > ws->part_bytes) S /= 2;
         if (S == 1) {
             hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) xblocks, kKsYB), dim3(256), 0, c->stream,
-                               (const uint32_t *) c->abart.p, (const int8_t *) c->kl, d_in, d_out, B, Bp, kj,
+                               (const uint32_t *) abart, (const int8_t *) c->kl, d_in, d_out, B, Bp, kj,
                                (uint32_t *) nullptr);
         } else {
-            HIPCHK(c->ks_part.reserve((size_t) S * Bp * kCt * sizeof(uint32_t)));
+            uint32_t *part;
+            if (ws) {
+                part = ws->part;
+            } else {
+                HIPCHK(c->ks_part.reserve((size_t) S * Bp * kCt * sizeof(uint32_t)));
+                part = (uint32_t *) c->ks_part.p;
+            }
             hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned) xblocks, kKsYB, (unsigned) S), dim3(256), 0, c->stream,
-                               (const uint32_t *) c->abart.p, (const int8_t *) c->kl, d_in, d_out, B, Bp, kj,
-                               (uint32_t *) c->ks_part.p);
+                               (const uint32_t *) abart, (const int8_t *) c->kl, d_in, d_out, B, Bp, kj, part);
             hipLaunchKernelGGL(k_ks_reduce, dim3((unsigned) ((B * kCt + 255) / 256)), dim3(256), 0, c->stream,
-                               (const uint32_t *) c->ks_part.p, S, d_in, d_out, B, Bp, kj);
+                               (const uint32_t *) part, S, d_in, d_out, B, Bp, kj);
         }
     } else {
         dim3 grid((unsigned) ((B + kKsG - 1) / kKsG));
@@ -1653,6 +1683,8 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     c->ka = make_phaseA_consts([&](int i) { return tw[i]; });
     const char *w = getenv("TFHE_HIP_BR_WAVES");
     if (w && (atoi(w) == 8 || atoi(w) == 4 || atoi(w) == 1 || atoi(w) == kShapeCoop)) c->br_waves = atoi(w);
+    const char *fc = getenv("TFHE_HIP_TEST_FAIL_CHUNK");
+    if (fc) c->fault_chunk = atoll(fc);
     const char *km = getenv("TFHE_HIP_KS_MFMA");
     if (km) c->ks_mfma = atoi(km) != 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -2021,12 +2053,35 @@ int tfhe_hip_internal_gate_batch(tfhe_hip_ctx *c, int gate, int *out, const int 
     if (b) HIPCHK(c->in_b.reserve(bytes));
     if (cc) HIPCHK(c->in_c.reserve(bytes));
     HIPCHK(c->outb.reserve(bytes));
+    // every work buffer at the size of the largest chunk BEFORE the first launch: growing one later would free memory
+    // that the kernels of the previous chunk may still be using (and stall the overlap on hipFree's implicit sync)
+    if (gate <= TFHE_HIP_MUX) {
+        HIPCHK(c->ext1.reserve((size_t) kChunk * kExt * sizeof(int32_t)));
+        if (gate == TFHE_HIP_MUX) HIPCHK(c->ext2.reserve((size_t) kChunk * kExt * sizeof(int32_t)));
+        const long long Bp = (kChunk + 32 * kKsMT - 1) / (32 * kKsMT) * (32 * kKsMT);
+        HIPCHK(c->abart.reserve((size_t) kN * Bp * sizeof(uint32_t)));
+        size_t part = 0;  // chunks are 2,048 or 4,096 gates or a ragged tail: the largest partial-sum buffer any needs
+        for (long long bp = 32 * kKsMT; bp <= Bp; bp += 32 * kKsMT) {
+            const int S = ks_split(bp);
+            if (S > 1) part = std::max<size_t>(part, (size_t) S * (size_t) bp * kCt * sizeof(uint32_t));
+        }
+        if (part) HIPCHK(c->ks_part.reserve(part));
+    }
     const int64_t nchunks = 1 + (count - kFirst + kChunk - 1) / kChunk;
     while ((int64_t) c->chunk_ev.size() < 3 * nchunks) {
         hipEvent_t ev;
         HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         c->chunk_ev.push_back(ev);
     }
+    // From here on asynchronous copies target the caller's buffers: no early return.  A failing HIP call records the
+    // error (hipfail), the loop stops, and both streams are drained before the function reports it.
+    auto hipfail = [&](hipError_t e, const char *what) -> int {
+        return e == hipSuccess ? TFHE_HIP_OK : fail(TFHE_HIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
+#define STEP(x)                                                \
+    do {                                                       \
+        if (int r_ = hipfail((x), #x)) return r_;              \
+    } while (0)
     auto span = [&](int64_t k, int64_t &off, int64_t &n) {
         off = k == 0 ? 0 : kFirst + (k - 1) * kChunk;
         const int64_t want = k == 0 ? kFirst : kChunk;
@@ -2037,48 +2092,59 @@ int tfhe_hip_internal_gate_batch(tfhe_hip_ctx *c, int gate, int *out, const int 
         span(k, off, n);
         if (fill) fill(user, off, n);
         const size_t o = (size_t) off * kCt, nb = (size_t) n * kCt * sizeof(int32_t);
-        if (a) HIPCHK(hipMemcpyAsync((int32_t *) c->in_a.p + o, a + o, nb, hipMemcpyHostToDevice, c->copy_stream));
-        if (b) HIPCHK(hipMemcpyAsync((int32_t *) c->in_b.p + o, b + o, nb, hipMemcpyHostToDevice, c->copy_stream));
-        if (cc) HIPCHK(hipMemcpyAsync((int32_t *) c->in_c.p + o, cc + o, nb, hipMemcpyHostToDevice, c->copy_stream));
-        HIPCHK(hipEventRecord(c->chunk_ev[3 * k], c->copy_stream));
+        if (a) STEP(hipMemcpyAsync((int32_t *) c->in_a.p + o, a + o, nb, hipMemcpyHostToDevice, c->copy_stream));
+        if (b) STEP(hipMemcpyAsync((int32_t *) c->in_b.p + o, b + o, nb, hipMemcpyHostToDevice, c->copy_stream));
+        if (cc) STEP(hipMemcpyAsync((int32_t *) c->in_c.p + o, cc + o, nb, hipMemcpyHostToDevice, c->copy_stream));
+        STEP(hipEventRecord(c->chunk_ev[3 * k], c->copy_stream));
         return TFHE_HIP_OK;
     };
     auto copy_out = [&](int64_t k) -> int {
         int64_t off, n;
         span(k, off, n);
         const size_t o = (size_t) off * kCt, nb = (size_t) n * kCt * sizeof(int32_t);
-        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->chunk_ev[3 * k + 1], 0));
-        HIPCHK(hipMemcpyAsync(out + o, (int32_t *) c->outb.p + o, nb, hipMemcpyDeviceToHost, c->copy_stream));
-        HIPCHK(hipEventRecord(c->chunk_ev[3 * k + 2], c->copy_stream));
+        STEP(hipStreamWaitEvent(c->copy_stream, c->chunk_ev[3 * k + 1], 0));
+        STEP(hipMemcpyAsync(out + o, (int32_t *) c->outb.p + o, nb, hipMemcpyDeviceToHost, c->copy_stream));
+        STEP(hipEventRecord(c->chunk_ev[3 * k + 2], c->copy_stream));
         return TFHE_HIP_OK;
     };
     auto drain_chunk = [&](int64_t k) -> int {
         if (!drain) return TFHE_HIP_OK;
         int64_t off, n;
         span(k, off, n);
-        HIPCHK(hipEventSynchronize(c->chunk_ev[3 * k + 2]));
+        STEP(hipEventSynchronize(c->chunk_ev[3 * k + 2]));
         drain(user, off, n);
         return TFHE_HIP_OK;
     };
-    int rc = copy_in(0);
-    for (int64_t k = 0; k < nchunks && rc == TFHE_HIP_OK; k++) {
+    auto run_chunk = [&](int64_t k) -> int {
         int64_t off, n;
         span(k, off, n);
         const size_t o = (size_t) off * kCt;
-        HIPCHK(hipStreamWaitEvent(c->stream, c->chunk_ev[3 * k], 0));
-        rc = tfhe_hip_gate_batch_dev(c, gate, (int32_t *) c->outb.p + o, a ? (const int32_t *) c->in_a.p + o : nullptr,
-                                     b ? (const int32_t *) c->in_b.p + o : nullptr,
-                                     cc ? (const int32_t *) c->in_c.p + o : nullptr, n);
-        if (rc != TFHE_HIP_OK) break;
-        HIPCHK(hipEventRecord(c->chunk_ev[3 * k + 1], c->stream));
-        if (k + 1 < nchunks) rc = copy_in(k + 1);
+        STEP(hipStreamWaitEvent(c->stream, c->chunk_ev[3 * k], 0));
+        if (c->fault_chunk >= 0 && k == c->fault_chunk) {  // test hook (TFHE_HIP_TEST_FAIL_CHUNK): a failure mid-pipeline
+            c->fault_chunk = -1;
+            return fail(TFHE_HIP_ERR_HIP, "injected failure (TFHE_HIP_TEST_FAIL_CHUNK)");
+        }
+        if (int r = tfhe_hip_gate_batch_dev(c, gate, (int32_t *) c->outb.p + o, a ? (const int32_t *) c->in_a.p + o : nullptr,
+                                            b ? (const int32_t *) c->in_b.p + o : nullptr,
+                                            cc ? (const int32_t *) c->in_c.p + o : nullptr, n))
+            return r;
+        STEP(hipEventRecord(c->chunk_ev[3 * k + 1], c->stream));
+        return TFHE_HIP_OK;
+    };
+#undef STEP
+    int rc = copy_in(0);
+    for (int64_t k = 0; k < nchunks && rc == TFHE_HIP_OK; k++) {
+        rc = run_chunk(k);
+        if (rc == TFHE_HIP_OK && k + 1 < nchunks) rc = copy_in(k + 1);
         if (rc == TFHE_HIP_OK && k > 0) rc = copy_out(k - 1);
         if (rc == TFHE_HIP_OK && k > 0) rc = drain_chunk(k - 1);
     }
     if (rc == TFHE_HIP_OK) rc = copy_out(nchunks - 1);
-    (void) hipStreamSynchronize(c->copy_stream);
+    const std::string first_error = rc == TFHE_HIP_OK ? std::string() : g_err;
+    (void) hipStreamSynchronize(c->copy_stream);  // nothing targets the caller's buffers once these two return
     (void) hipStreamSynchronize(c->stream);
     if (rc == TFHE_HIP_OK) rc = drain_chunk(nchunks - 1);
+    else g_err = first_error;
     return rc;
 }
 
@@ -2424,9 +2490,8 @@ int tfhe_hip_netlist_create(tfhe_hip_ctx *c, tfhe_hip_netlist **out, int32_t *d_
         ks.insert(ks.end(), c->h_ks.begin(), c->h_ks.end());
         lin.insert(lin.end(), c->h_lin.begin(), c->h_lin.end());
         if (lv.nbr) {  // workspace of this level, as launch_ks sizes it
-            const long long Bp = (lv.nks + 32 * kKsMT - 1) / (32 * kKsMT) * (32 * kKsMT), xblocks = Bp / (32 * kKsMT);
-            int S = 1;
-            while (S < 16 && kKsYB * xblocks * S < 256) S *= 2;
+            const long long Bp = (lv.nks + 32 * kKsMT - 1) / (32 * kKsMT) * (32 * kKsMT);
+            const int S = ks_split(Bp);
             ext_b = std::max(ext_b, (size_t) lv.nbr * kExt * sizeof(int32_t));
             abart_b = std::max(abart_b, (size_t) ((size_t) kN * (size_t) Bp * sizeof(uint32_t)));
             if (S > 1) part_b = std::max(part_b, (size_t) ((size_t) S * (size_t) Bp * kCt * sizeof(uint32_t)));

@@ -308,7 +308,7 @@ class Engine:
         """draw, transform and install the bootstrapping key on the device; returns its coefficient form if asked"""
         lk = _i32(lwe_key, (self.params.n,)).reshape(-1)
         tk = _i32(tlwe_key, (self.params.N,)).reshape(-1)
-        ks = np.ascontiguousarray(ks, dtype=np.int32)
+        ks = None if ks is None else np.ascontiguousarray(ks, dtype=np.int32)   # None: keep the key on the device
         out = np.empty((self.params.n, self.params.kpl, 2, self.params.N), np.int32) if want_coef else None
         self._chk(self.lib.tfhe_hip_keygen_bk(self.ctx, ctypes.c_uint64(seed), _p(lk), _p(tk), _p(ks),
                                               _p(out) if want_coef else None), "keygen_bk")

@@ -92,11 +92,21 @@ def run_levels_sharded(level_fn, pool, levels):
     dist = _dist()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     total = 0
+
+    def order_streams():
+        # STREAM CONTRACT of every *_dev entry point: the engine launches on its own non-blocking stream
+        # (tfhe_hip_stream), which is not ordered with torch's current stream nor with the collective's.  Whatever torch
+        # wrote into `pool` (the scatter of the gathered rows below, the caller's input rows) must have landed before
+        # level_fn reads it; Engine.gate_level_dev itself returns only after its level has completed.
+        if pool.is_cuda:
+            torch.cuda.current_stream(pool.device).synchronize()
+
     for lv in levels:
         lv = np.ascontiguousarray(lv, dtype=np.int32).reshape(-1, 5)
         count = lv.shape[0]
         total += count
         lo, hi = shard_bounds(count, rank, world)
+        order_streams()
         if hi > lo:
             level_fn(lv[lo:hi])
         if world == 1:
@@ -111,4 +121,5 @@ def run_levels_sharded(level_fn, pool, levels):
             rlo, rhi = shard_bounds(count, r, world)
             if r != rank and rhi > rlo:
                 pool[torch.from_numpy(lv[rlo:rhi, 1].astype(np.int64)).to(pool.device)] = parts[r][:rhi - rlo]
+    order_streams()
     return total
