@@ -124,6 +124,15 @@ int tfhe_hip_gate_batch_dev(tfhe_hip_ctx *ctx, int gate, int32_t *d_out, const i
 int tfhe_hip_bootstrap_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_in, int32_t mu, int64_t count,
                                  int with_ks);
 int tfhe_hip_keyswitch_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_in, int64_t count);
+/* tfhe_hip_gate_batch_dev for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, semantics and results as
+ * tfhe_hip_gate_batch_dev, but the work buffers (extracted samples, keyswitch workspace) are slices of a static
+ * device array of the library (about 21 MB per GPU, held until the process ends) instead of growable allocations:
+ * the call performs no hipMalloc / hipFree.  count > TFHE_HIP_NOALLOC_MAX_GATES is rejected with TFHE_HIP_ERR_ARG.
+ * All calls on one GPU share that array: calls that overlap on one GPU (two contexts, two streams) race. */
+#define TFHE_HIP_NOALLOC_MAX_GATES 1024
+int tfhe_hip_gate_batch_dev_noalloc(tfhe_hip_ctx *ctx, int gate, int32_t *d_out, const int32_t *d_a, const int32_t *d_b,
+                                    const int32_t *d_c, int64_t count);
 int tfhe_hip_sync(tfhe_hip_ctx *ctx);
 /* raw stream handle (hipStream_t) so that callers can record events on the stream the kernels run on */
 void *tfhe_hip_stream(tfhe_hip_ctx *ctx);

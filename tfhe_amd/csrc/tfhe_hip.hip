@@ -1436,6 +1436,41 @@ bool build_twiddles(std::vector<c64> &tw) {
     return h == kTwFingerprint;
 }
 
+// ---- static scratch of the entry point that allocates nothing (tfhe_hip_gate_batch_dev_noalloc) --------------------
+// One copy per GPU the library runs on, held until the process ends.  Regions (256-byte aligned): extracted samples of
+// the first and (MUX) second blind rotation, the keyswitch's transposed input, its partial sums.  Every call on a GPU
+// shares the array; nothing in it has to start at zero (each region is fully written before it is read: the blind
+// rotation writes every extracted row it later reads, k_ks_transpose every abarT column incl. the padding ciphertexts,
+// k_keyswitch_mfma every partial sum that k_ks_reduce adds), but calls that overlap on one GPU race.
+constexpr size_t na_align(size_t b) { return (b + 255) / 256 * 256; }
+constexpr size_t kNaMaxGates = TFHE_HIP_NOALLOC_MAX_GATES;
+constexpr size_t kNaMaxBp = (kNaMaxGates + 32 * kKsMT - 1) / (32 * kKsMT) * (32 * kKsMT);
+constexpr size_t kNaExtBytes = na_align(kNaMaxGates * (kN + 1) * sizeof(int32_t));
+constexpr size_t kNaAbartBytes = na_align((size_t) kN * kNaMaxBp * sizeof(uint32_t));
+constexpr size_t kNaPartBytes = (size_t) 8 << 20;
+constexpr size_t kNaExt1Off = 0, kNaExt2Off = kNaExtBytes, kNaAbartOff = 2 * kNaExtBytes, kNaPartOff = kNaAbartOff + kNaAbartBytes;
+constexpr size_t kNaTotalBytes = kNaPartOff + kNaPartBytes;
+static __device__ __align__(256) unsigned char g_noalloc_scratch[kNaTotalBytes];
+// g_noalloc_scratch is a host-side stand-in here, not a device address: host code only ever uses the per-device pointer
+constexpr int kNaMaxDevices = 64;
+unsigned char *g_na_ptr[kNaMaxDevices];
+std::mutex g_na_mu;
+// with `device` current: resolve this device's copy of the array once
+hipError_t noalloc_scratch_init(int device) {
+    if (device < 0 || device >= kNaMaxDevices) return hipSuccess;  // beyond the table: the no-alloc entry point reports it
+    std::lock_guard<std::mutex> lock(g_na_mu);
+    if (g_na_ptr[device]) return hipSuccess;
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch));
+    if (e == hipSuccess) g_na_ptr[device] = (unsigned char *) p;
+    return e;
+}
+unsigned char *noalloc_scratch_ptr(int device) {
+    if (device < 0 || device >= kNaMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_na_mu);
+    return g_na_ptr[device];
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -1678,6 +1713,7 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     if (!build_twiddles(tw))
         return fail(TFHE_HIP_ERR_TABLE, "twiddle table fingerprint mismatch: host libm cos/sin round differently");
     HIPCHK(hipSetDevice(device));
+    HIPCHK(noalloc_scratch_init(device));
     tfhe_hip_ctx *c = new tfhe_hip_ctx();
     c->device = device;
     c->ka = make_phaseA_consts([&](int i) { return tw[i]; });
@@ -1946,8 +1982,13 @@ int tfhe_hip_keyswitch_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const int32_t 
     return TFHE_HIP_OK;
 }
 
-int tfhe_hip_gate_batch_dev(tfhe_hip_ctx *c, int gate, int32_t *d_out, const int32_t *d_a, const int32_t *d_b,
-                            const int32_t *d_c, int64_t count) {
+// work buffers of one gate batch: the extracted samples of the one or (MUX) two blind rotations, and the keyswitch's
+struct GateWork {
+    int32_t *ext1, *ext2;
+    KsWork ks;
+};
+static int gate_batch_dev_impl(tfhe_hip_ctx *c, int gate, int32_t *d_out, const int32_t *d_a, const int32_t *d_b,
+                               const int32_t *d_c, int64_t count, const GateWork *gw) {
     if (int r = check_ctx(c, gate <= TFHE_HIP_MUX)) return r;
     if (gate < TFHE_HIP_NAND || gate > TFHE_HIP_CONST0) return fail(TFHE_HIP_ERR_ARG, "unknown gate id");
     if (count < 0 || (count > 0 && !d_out)) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
@@ -1965,33 +2006,66 @@ int tfhe_hip_gate_batch_dev(tfhe_hip_ctx *c, int gate, int32_t *d_out, const int
         HIPCHK(hipGetLastError());
         return TFHE_HIP_OK;
     }
-    HIPCHK(c->ext1.reserve((size_t) count * kExt * sizeof(int32_t)));
+    int32_t *ext1, *ext2 = nullptr;
+    if (gw) {
+        ext1 = gw->ext1;
+        ext2 = gw->ext2;
+    } else {
+        HIPCHK(c->ext1.reserve((size_t) count * kExt * sizeof(int32_t)));
+        ext1 = (int32_t *) c->ext1.p;
+        if (gate == TFHE_HIP_MUX) {
+            HIPCHK(c->ext2.reserve((size_t) count * kExt * sizeof(int32_t)));
+            ext2 = (int32_t *) c->ext2.p;
+        }
+    }
     BrArgs A{};
     A.mu = kMU; A.bk = c->bk; A.tw = c->tw; A.ka = c->ka; A.B = count;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     if (gate == TFHE_HIP_MUX) {  // boot-gates.cpp:329-370
-        HIPCHK(c->ext2.reserve((size_t) count * kExt * sizeof(int32_t)));
-        A.a = d_a; A.b = d_b; A.sa = 1; A.sb = 1; A.cst = -kMU; A.out = (int32_t *) c->ext1.p;
+        A.a = d_a; A.b = d_b; A.sa = 1; A.sb = 1; A.cst = -kMU; A.out = ext1;
         if (int r = launch_br<MODE_GATE>(c, A)) return r;
-        A.a = d_a; A.b = d_c; A.sa = -1; A.sb = 1; A.cst = -kMU; A.out = (int32_t *) c->ext2.p;
+        A.a = d_a; A.b = d_c; A.sa = -1; A.sb = 1; A.cst = -kMU; A.out = ext2;
         if (int r = launch_br<MODE_GATE>(c, A)) return r;
         const long long total = (long long) count * kExt;
-        hipLaunchKernelGGL(k_mux_combine, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream,
-                           (int32_t *) c->ext1.p, (const int32_t *) c->ext2.p, kMU, total);
+        hipLaunchKernelGGL(k_mux_combine, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream, ext1,
+                           (const int32_t *) ext2, kMU, total);
         HIPCHK(hipGetLastError());
     } else {
         GateLin g;
         gate_lin(gate, g);
-        A.a = d_a; A.b = d_b; A.sa = g.sa; A.sb = g.sb; A.cst = g.cst; A.out = (int32_t *) c->ext1.p;
+        A.a = d_a; A.b = d_b; A.sa = g.sa; A.sb = g.sb; A.cst = g.cst; A.out = ext1;
         if (int r = launch_br<MODE_GATE>(c, A)) return r;
     }
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     c->ev_br = true;
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
-    if (int r = launch_ks(c, d_out, (const int32_t *) c->ext1.p, count)) return r;
+    if (int r = launch_ks(c, d_out, (const int32_t *) ext1, count, nullptr, gw ? &gw->ks : nullptr)) return r;
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
     c->ev_ks = true;
     return TFHE_HIP_OK;
+}
+
+int tfhe_hip_gate_batch_dev(tfhe_hip_ctx *c, int gate, int32_t *d_out, const int32_t *d_a, const int32_t *d_b,
+                            const int32_t *d_c, int64_t count) {
+    return gate_batch_dev_impl(c, gate, d_out, d_a, d_b, d_c, count, nullptr);
+}
+
+// ---- the entry point that allocates nothing (include/tfhe_hip.h) ---------------------------------------------------
+// Work buffers = slices of the file-scope device array g_noalloc_scratch; its per-device address is looked up once per
+// device in tfhe_hip_create (noalloc_scratch_init) and only that pointer is ever handed to kernels.
+int tfhe_hip_gate_batch_dev_noalloc(tfhe_hip_ctx *c, int gate, int32_t *d_out, const int32_t *d_a, const int32_t *d_b,
+                                    const int32_t *d_c, int64_t count) {
+    if (!c) return fail(TFHE_HIP_ERR_ARG, "null context");
+    if (count > TFHE_HIP_NOALLOC_MAX_GATES)
+        return fail(TFHE_HIP_ERR_ARG, "tfhe_hip_gate_batch_dev_noalloc: count exceeds TFHE_HIP_NOALLOC_MAX_GATES (" +
+                                          std::to_string(TFHE_HIP_NOALLOC_MAX_GATES) + ")");
+    unsigned char *base = noalloc_scratch_ptr(c->device);
+    if (!base) return fail(TFHE_HIP_ERR_HIP, "the static scratch array of this device was not resolved at tfhe_hip_create");
+    GateWork gw;
+    gw.ext1 = (int32_t *) (base + kNaExt1Off);
+    gw.ext2 = (int32_t *) (base + kNaExt2Off);
+    gw.ks = KsWork{(uint32_t *) (base + kNaAbartOff), kNaAbartBytes, (uint32_t *) (base + kNaPartOff), kNaPartBytes};
+    return gate_batch_dev_impl(c, gate, d_out, d_a, d_b, d_c, count, &gw);
 }
 
 int tfhe_hip_last_kernel_ms(tfhe_hip_ctx *c, float *br_ms, float *ks_ms) {

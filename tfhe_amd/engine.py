@@ -64,7 +64,7 @@ EXPORTS = [
     "tfhe_hip_negacyclic_mul2048_batch", "tfhe_hip_negacyclic_mul2048_batch_dev",
     "tfhe_hip_encrypt_batch", "tfhe_hip_encrypt_batch_dev", "tfhe_hip_phase_batch", "tfhe_hip_keygen_bk",
     "tfhe_hip_param_set", "tfhe_hip_netlist_create", "tfhe_hip_netlist_run", "tfhe_hip_netlist_is_graph",
-    "tfhe_hip_netlist_destroy", "tfhe_hip_keygen_cloud",
+    "tfhe_hip_netlist_destroy", "tfhe_hip_keygen_cloud", "tfhe_hip_gate_batch_dev_noalloc",
 ]
 
 
@@ -232,6 +232,12 @@ class Engine:
     def gate_batch_dev(self, gate, out, a=None, b=None, c=None, count=None):
         self._chk(self.lib.tfhe_hip_gate_batch_dev(self.ctx, int(gate), self._dptr(out), self._dptr(a), self._dptr(b),
                                                    self._dptr(c), ctypes.c_int64(count)), "gate_batch_dev")
+
+    def gate_batch_dev_noalloc(self, gate, out, a=None, b=None, c=None, count=None):
+        """tfhe_hip_gate_batch_dev_noalloc: same results, work buffers in the library's static device array"""
+        self._chk(self.lib.tfhe_hip_gate_batch_dev_noalloc(self.ctx, int(gate), self._dptr(out), self._dptr(a),
+                                                           self._dptr(b), self._dptr(c), ctypes.c_int64(count)),
+                  "gate_batch_dev_noalloc")
 
     def bootstrap_batch_dev(self, out, x, count, mu=PARAMS.MU, with_ks=True):
         self._chk(self.lib.tfhe_hip_bootstrap_batch_dev(self.ctx, self._dptr(out), self._dptr(x), ctypes.c_int32(mu),
