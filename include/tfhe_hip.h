@@ -94,6 +94,23 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device);
 void tfhe_hip_destroy(tfhe_hip_ctx *ctx);
 const char *tfhe_hip_last_error(void);
 
+/* Arithmetic of the FP64 stage, per context (default EXACT; $TFHE_HIP_ARITH=fast makes FAST the default of new
+ * contexts).  The reference has no counterpart: its transform is fixed (src/libtfhe/polynomials.cpp:13-175).
+ *   EXACT  every ciphertext equals the reference CPU path's bit for bit (the reference's 2048-point radix-2 transform,
+ *          operation by operation, no FMA).
+ *   FAST   the same negacyclic transforms in their minimal form (512 complex points in both directions, fused
+ *          multiply-adds): decrypted bits identical, Torus32 coefficients within the tolerances of the reference's own
+ *          tests - forward spectra |delta| <= 1e-10 (src/test/test-MulToTLwe.cpp:365-371), FFT products within 1 LSB of
+ *          the exact product (src/test/test-multiplication.cpp:66-77), an external product within 4 LSB of the
+ *          reference's, the phase of a bootstrapped sample within 2^22 LSB (2^-10) of the reference's; keyswitch and all
+ *          integer stages stay exact.  About 1.6x the gate throughput.  Batches of up to 256 bootstraps run the latency
+ *          kernel, which is exact arithmetic in both modes.
+ * The call waits for the context's stream; with keys loaded it derives the FAST key (a re-indexing of the same
+ * doubles, 62 MB more device memory). */
+enum { TFHE_HIP_ARITH_EXACT = 0, TFHE_HIP_ARITH_FAST = 1 };
+int tfhe_hip_set_arithmetic(tfhe_hip_ctx *ctx, int mode);
+int tfhe_hip_get_arithmetic(tfhe_hip_ctx *ctx);
+
 /* Key upload.  Replaces the per-call copy of the whole bkFFT into the OpenCL buffer
  * (lwe-bootstrapping-functions-fft.cpp:112-133) by a one-time upload.
  * _coef : takes the coefficient-domain TGSW key and performs tGswToFFTConvert on the GPU

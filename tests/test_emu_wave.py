@@ -13,3 +13,14 @@ def test_kernel_arithmetic_on_host(tmp_path):
                     "-Wl,-rpath," + os.path.join(ROOT, "oracle")], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "EMU OK" in out
+
+
+def test_fast_mode_arithmetic_on_host(tmp_path):
+    """tests/emu/emu_fast.cpp: the per-lane routines of tfhe_amd/csrc/fast_core.h (FAST arithmetic mode) against the
+    oracle within the tolerances of the reference's own stage tests"""
+    exe = str(tmp_path / "emu_fast")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-mfma", "-ffp-contract=off", "-o", exe,
+                    os.path.join(ROOT, "tests", "emu", "emu_fast.cpp"), "-L" + os.path.join(ROOT, "oracle"), "-loracle",
+                    "-Wl,-rpath," + os.path.join(ROOT, "oracle")], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "EMU FAST OK" in out

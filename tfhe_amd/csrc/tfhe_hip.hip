@@ -22,6 +22,7 @@
 #include <memory>
 #include <vector>
 #include "br_core.h"
+#include "fast_core.h"
 #include "internal.h"
 #include "../../include/tfhe_hip.h"
 
@@ -154,8 +155,8 @@ __device__ __forceinline__ void cmac(c64 &acc, const c64 a, const c64 b) {
     acc.im += ad + bc;
 }
 
-__device__ __forceinline__ void load_tw_to_lds(c64 *tw_lds, const c64 *tw) {
-    for (int i = threadIdx.x; i < kTwLaneEntries; i += blockDim.x) tw_lds[i] = tw[i];
+__device__ __forceinline__ void load_tw_to_lds(c64 *tw_lds, const c64 *tw, int entries = kTwLaneEntries) {
+    for (int i = threadIdx.x; i < entries; i += blockDim.x) tw_lds[i] = tw[i];
     __syncthreads();
 }
 
@@ -422,14 +423,197 @@ __device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int b
     wave_sync();
 }
 
-template <int MODE, int WAVES>
+// ---------------------------------------------------------------------------------------------------------------
+// FAST arithmetic mode (fast_core.h): the same CMux with folded 512-point transforms in both directions and fused
+// multiply-adds.  Same pipeline as above: the MAC of transform t-1 in the transpose gaps of transform t; the two inverse
+// transforms, now of the forward transform's shape, alternate on the scratch so that each one's transposes are covered
+// by the other's butterflies.  The summed spectra enter the inverse transforms by register renaming (no exchange).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mac_col_f(c64 (&acc)[8], const c64 (&v)[8], const c64 (&kb)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) brf::cmac(acc[r], v[r], kb[r]);
+}
+__device__ __forceinline__ void t_write_A(c64 *scratch, const c64 (&v)[8], int lane) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) scratch[swz(fwd_xA(lane, r))] = v[r];
+}
+__device__ __forceinline__ void t_write_B(c64 *scratch, const c64 (&v)[8], int lane) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) scratch[swz(fwd_xB(lane, r))] = v[r];
+}
+__device__ __forceinline__ void t_read_B(c64 (&v)[8], const c64 *scratch, int lane) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xB(lane, r))];
+}
+__device__ __forceinline__ void t_read_C(c64 (&v)[8], const c64 *scratch, int lane) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xC(lane, r))];
+}
+__device__ __forceinline__ void wave_fwd_fast(c64 (&v)[8], int lane, c64 *scratch, const PhaseAConsts &twu, const TwLds &twl) {
+    brf::fwd_phaseA(v, twu);
+    t_write_A(scratch, v, lane);
+    wave_sync();
+    t_read_B(v, scratch, lane);
+    wave_sync();
+    brf::fwd_phaseBC<brf::FS_FB>(v, twl);
+    t_write_B(scratch, v, lane);
+    wave_sync();
+    t_read_C(v, scratch, lane);
+    wave_sync();
+    brf::fwd_phaseBC<brf::FS_FC>(v, twl);
+}
+// s: spectrum as the forward transform leaves it (register r = Y_(r<<6|lane)); lo/hi: coefficients j = r<<6|lane, j + 512
+template <bool BOUNDED>
+__device__ __forceinline__ void wave_inv_fast(int32_t (&lo)[8], int32_t (&hi)[8], const c64 (&s)[8], int lane, c64 *scratch,
+                                              const PhaseAConsts &twu, const TwLds &twl) {
+    c64 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = s[br3(r)];
+    brf::inv_phaseA(v, twu);
+    t_write_A(scratch, v, lane);
+    wave_sync();
+    t_read_B(v, scratch, lane);
+    wave_sync();
+    brf::inv_phaseBC<brf::FS_IB>(v, twl);
+    t_write_B(scratch, v, lane);
+    wave_sync();
+    t_read_C(v, scratch, lane);
+    wave_sync();
+    brf::inv_phaseBC<brf::FS_IC>(v, twl);
+    brf::inv_final<BOUNDED>(lo, hi, v, twl);
+}
+
+template <bool ROTATE>
+__device__ __forceinline__ void fwd_step_fast(const int t, c64 (&v)[8], const c64 (&pv)[8], c64 (&tmpa)[2][8],
+                                              c64 (&kb)[8], uint32_t (&tlo)[8], uint32_t (&thi)[8], const int32_t *acc,
+                                              c64 *scratch, int lane, int bara, const c64 *bki, const PhaseAConsts &twu,
+                                              const TwLds &twl) {
+    const int c = t >= kL ? 1 : 0, p = t - c * kL;
+    if (p == 0) {
+        const int32_t *accc = acc + c * kN;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int j = (br3(r) << 6) | lane;
+            if (ROTATE) {
+                tlo[r] = decomp_prepare(rot_minus_one(accc, bara, j));
+                thi[r] = decomp_prepare(rot_minus_one(accc, bara, j + kNh));
+            } else {
+                tlo[r] = decomp_prepare(accc[j]);
+                thi[r] = decomp_prepare(accc[j + kNh]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = {(double) decomp_digit_rt(tlo[r], p), (double) decomp_digit_rt(thi[r], p)};
+    const c64 *row = bki + (size_t) (t * 2) * kNh + lane;
+    brf::fwd_phaseA(v, twu);
+    prio_exchange();
+    t_write_A(scratch, v, lane);
+    wave_sync();
+    if (t > 0) {
+        mac_col_f(tmpa[0], pv, kb);
+        load_col(kb, row - kNh);
+    }
+    prio_compute();
+    t_read_B(v, scratch, lane);
+    wave_sync();
+    brf::fwd_phaseBC<brf::FS_FB>(v, twl);
+    prio_exchange();
+    t_write_B(scratch, v, lane);
+    wave_sync();
+    if (t > 0) mac_col_f(tmpa[1], pv, kb);
+    load_col(kb, row);
+    prio_compute();
+    t_read_C(v, scratch, lane);
+    wave_sync();
+    brf::fwd_phaseBC<brf::FS_FC>(v, twl);
+}
+
+template <bool ROTATE>
+__device__ __forceinline__ void cmux_fast(int32_t *acc, c64 *scratch, int lane, int bara, const c64 *bki,
+                                          const PhaseAConsts &twu, const TwLds &twl) {
+    c64 tmpa[2][8], kb[8], va[8], vb[8];
+    uint32_t tlo[8], thi[8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) tmpa[c][r] = {0.0, 0.0};
+#pragma unroll 1
+    for (int t = 0; t < 2 * kL; t += 2) {
+        fwd_step_fast<ROTATE>(t, va, vb, tmpa, kb, tlo, thi, acc, scratch, lane, bara, bki, twu, twl);
+        fwd_step_fast<ROTATE>(t + 1, vb, va, tmpa, kb, tlo, thi, acc, scratch, lane, bara, bki, twu, twl);
+    }
+    // tail of the forward pipeline, then the inverse transforms A (column 0) and B (column 1)
+    c64 xa[8], xb[8];
+    mac_col_f(tmpa[0], vb, kb);
+    load_col(kb, bki + (size_t) (2 * kKpl - 1) * kNh + lane);
+#pragma unroll
+    for (int r = 0; r < 8; r++) xa[r] = tmpa[0][br3(r)];
+    brf::inv_phaseA(xa, twu);
+    prio_exchange();
+    t_write_A(scratch, xa, lane);
+    wave_sync();
+    mac_col_f(tmpa[1], vb, kb);
+#pragma unroll
+    for (int r = 0; r < 8; r++) xb[r] = tmpa[1][br3(r)];
+    brf::inv_phaseA(xb, twu);
+    prio_compute();
+    t_read_B(xa, scratch, lane);
+    wave_sync();
+    prio_exchange();
+    t_write_A(scratch, xb, lane);
+    wave_sync();
+    brf::inv_phaseBC<brf::FS_IB>(xa, twl);
+    prio_compute();
+    t_read_B(xb, scratch, lane);
+    wave_sync();
+    prio_exchange();
+    t_write_B(scratch, xa, lane);
+    wave_sync();
+    brf::inv_phaseBC<brf::FS_IB>(xb, twl);
+    prio_compute();
+    t_read_C(xa, scratch, lane);
+    wave_sync();
+    prio_exchange();
+    t_write_B(scratch, xb, lane);
+    wave_sync();
+    brf::inv_phaseBC<brf::FS_IC>(xa, twl);
+    {
+        int32_t lo[8], hi[8];
+        brf::inv_final<true>(lo, hi, xa, twl);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int j = (r << 6) | lane;
+            acc[j] = ROTATE ? (int32_t) ((uint32_t) acc[j] + (uint32_t) lo[r]) : lo[r];
+            acc[j + kNh] = ROTATE ? (int32_t) ((uint32_t) acc[j + kNh] + (uint32_t) hi[r]) : hi[r];
+        }
+    }
+    prio_compute();
+    t_read_C(xb, scratch, lane);
+    wave_sync();
+    brf::inv_phaseBC<brf::FS_IC>(xb, twl);
+    {
+        int32_t lo[8], hi[8];
+        brf::inv_final<true>(lo, hi, xb, twl);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int j = (r << 6) | lane;
+            acc[kN + j] = ROTATE ? (int32_t) ((uint32_t) acc[kN + j] + (uint32_t) lo[r]) : lo[r];
+            acc[kN + j + kNh] = ROTATE ? (int32_t) ((uint32_t) acc[kN + j + kNh] + (uint32_t) hi[r]) : hi[r];
+        }
+    }
+    wave_sync();
+}
+
+template <int MODE, int WAVES, bool FAST = false>
 __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
-    load_tw_to_lds(tw_lds, A.tw);
+    constexpr int kTwImage = FAST ? brf::kFastLaneEntries : kTwLaneEntries;  // A.tw is the image of the mode
+    load_tw_to_lds(tw_lds, A.tw, kTwImage);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    unsigned char *mine = lds_raw + kTwLaneEntries * sizeof(c64) + (size_t) wave * kBrLdsPerWave;
+    unsigned char *mine = lds_raw + kTwImage * sizeof(c64) + (size_t) wave * kBrLdsPerWave;
     int32_t *acc = reinterpret_cast<int32_t *>(mine);
     c64 *scratch = reinterpret_cast<c64 *>(mine + 2 * kN * 4);
     const long long g = (long long) blockIdx.x * WAVES + wave;
@@ -473,7 +657,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
         for (int i = 0; i < kLwe; i++) {
             const int bara = __builtin_amdgcn_readfirstlane(modswitch_2N(comb(i)));
             if (bara == 0) continue;  // lwe-bootstrapping-functions-fft.cpp:154
-            cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+            if (FAST) cmux_fast<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+            else cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
         }
 #ifdef TFHE_HIP_CLOCK_DIAG
         if (A.diag && lane == 0) {
@@ -501,11 +686,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
             for (int i = 0; i < kLwe; i++) {
                 const int bara = __builtin_amdgcn_readfirstlane(gbara[i]) & (2 * kN - 1);
                 if (bara == 0) continue;
-                cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+                if (FAST) cmux_fast<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+                else cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
             }
         } else {
             const int i = __builtin_amdgcn_readfirstlane(A.bara[g]);
-            cmux<false>(acc, scratch, lane, 0, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+            if (FAST) cmux_fast<false>(acc, scratch, lane, 0, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+            else cmux<false>(acc, scratch, lane, 0, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
         }
 #pragma unroll
         for (int q = 0; q < 32; q++) io[q * 64 + lane] = acc[q * 64 + lane];
@@ -1178,6 +1365,100 @@ __global__ __launch_bounds__(256) void k_poly_mul(const int32_t *__restrict__ ip
     for (int rho = 0; rho < 16; rho++) out[poly * kN + inv_yC(lane, rho)] = res[rho];
 }
 
+// ---- the same stages in the FAST arithmetic mode (fast_core.h); spectra cross the ABI in the reference order ----------
+constexpr int kFftLdsFast = brf::kFastLaneEntries * (int) sizeof(c64) + 4 * kNh * (int) sizeof(c64);
+__global__ __launch_bounds__(256) void k_poly_fwd_fast(const int32_t *__restrict__ polys, c64 *__restrict__ spectra,
+                                                       const c64 *__restrict__ tw, PhaseAConsts ka, long long count, int torus) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
+    load_tw_to_lds(tw_lds, tw, brf::kFastLaneEntries);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + brf::kFastLaneEntries * sizeof(c64)) + wave * kNh;
+    const long long poly = (long long) blockIdx.x * 4 + wave;
+    if (poly >= count) return;
+    const int32_t *p = polys + poly * kN;
+    const double s = torus ? 1.0 / 4294967296.0 : 1.0;
+    c64 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int j = (br3(r) << 6) | lane;
+        v[r] = {p[j] * s, p[j + kNh] * s};
+    }
+    wave_fwd_fast(v, lane, scratch, ka, TwLds{tw_lds + lane});
+#pragma unroll
+    for (int r = 0; r < 8; r++) {  // Z_k -> reference slots: C[2k] = Z_k (k < 256), C[1023 - 2k] = conj(Z_k) (k >= 256)
+        const int k = (r << 6) | lane;
+        spectra[poly * kNh + (k < kNh / 2 ? 2 * k : kN - 1 - 2 * k)] = k < kNh / 2 ? v[r] : c64{v[r].re, -v[r].im};
+    }
+}
+__device__ __forceinline__ c64 fast_from_ref(const c64 *C, int k) {
+    if (k < kNh / 2) return C[2 * k];
+    const c64 t = C[kN - 1 - 2 * k];
+    return {t.re, -t.im};
+}
+__global__ __launch_bounds__(256) void k_poly_inv_fast(const c64 *__restrict__ spectra, int32_t *__restrict__ polys,
+                                                       const c64 *__restrict__ tw, PhaseAConsts ka, long long count) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
+    load_tw_to_lds(tw_lds, tw, brf::kFastLaneEntries);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + brf::kFastLaneEntries * sizeof(c64)) + wave * kNh;
+    const long long poly = (long long) blockIdx.x * 4 + wave;
+    if (poly >= count) return;
+    c64 sp[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) sp[r] = fast_from_ref(spectra + poly * kNh, (r << 6) | lane);
+    int32_t lo[8], hi[8];
+    wave_inv_fast<false>(lo, hi, sp, lane, scratch, ka, TwLds{tw_lds + lane});
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        polys[poly * kN + ((r << 6) | lane)] = lo[r];
+        polys[poly * kN + ((r << 6) | lane) + kNh] = hi[r];
+    }
+}
+__global__ __launch_bounds__(256) void k_poly_mul_fast(const int32_t *__restrict__ ipolys, const int32_t *__restrict__ tpolys,
+                                                       int32_t *__restrict__ out, const c64 *__restrict__ tw,
+                                                       PhaseAConsts ka, long long count) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
+    load_tw_to_lds(tw_lds, tw, brf::kFastLaneEntries);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + brf::kFastLaneEntries * sizeof(c64)) + wave * kNh;
+    const long long poly = (long long) blockIdx.x * 4 + wave;
+    if (poly >= count) return;
+    const TwLds twl{tw_lds + lane};
+    c64 a[8], b[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int j = (br3(r) << 6) | lane;
+        a[r] = {(double) ipolys[poly * kN + j], (double) ipolys[poly * kN + j + kNh]};
+        b[r] = {tpolys[poly * kN + j] * (1.0 / 4294967296.0), tpolys[poly * kN + j + kNh] * (1.0 / 4294967296.0)};
+    }
+    wave_fwd_fast(a, lane, scratch, ka, twl);
+    wave_fwd_fast(b, lane, scratch, ka, twl);
+#pragma unroll
+    for (int r = 0; r < 8; r++) a[r] = brf::cmul(a[r], b[r]);
+    int32_t lo[8], hi[8];
+    wave_inv_fast<false>(lo, hi, a, lane, scratch, ka, twl);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        out[poly * kN + ((r << 6) | lane)] = lo[r];
+        out[poly * kN + ((r << 6) | lane) + kNh] = hi[r];
+    }
+}
+// bootstrapping key of the FAST mode from the exact mode's (physical slot x holds reference bin igray(x)): the same
+// doubles, re-indexed to Z_k order [poly][k] and conjugated where the fold asks for it - no arithmetic, so the key is
+// the reference's bkFFT bit for bit in both modes
+__global__ void k_bk_to_fast(c64 *__restrict__ dst, const c64 *__restrict__ src, long long total) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long poly = i >> 9;
+    const int k = (int) (i & 511);
+    const int bin = k < kNh / 2 ? 2 * k : kN - 1 - 2 * k;
+    const c64 t = src[poly * kNh + gray(bin)];
+    dst[i] = k < kNh / 2 ? t : c64{t.re, -t.im};
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // N = 2048 negacyclic product (BASELINE configs[4] microbench) from four N = 1024 products.  With Y = X^2,
 // a = a_e(Y) + X a_o(Y) and b alike:  a b = (a_e b_e + Y a_o b_o)(Y) + X (a_e b_o + a_o b_e)(Y)  mod X^2048 + 1, and
@@ -1499,6 +1780,9 @@ struct tfhe_hip_ctx {
     std::vector<hipEvent_t> chunk_ev;       // per chunk: inputs landed, kernels done
     c64 *tw = nullptr;
     PhaseAConsts ka{};
+    int arith = TFHE_HIP_ARITH_EXACT;  // tfhe_hip_set_arithmetic
+    c64 *twf = nullptr;      // per-lane twiddle image of the FAST mode (fast_core.h)
+    c64 *bkf = nullptr;      // FAST mode: [n][6][2][512] in Z_k order, built from bk when the mode is selected
     c64 *bk = nullptr;       // [n][6][2][512] physical order
     int32_t *ks = nullptr;   // [N][t][3][632]   (VALU keyswitch, kept for the ragged tail / A-B checks)
     int8_t *kl = nullptr;    // [N][4][640][t][4] byte limbs (MFMA keyswitch)
@@ -1558,9 +1842,12 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
     // (measured, default set, ms for 256 / 512 / 768 / 1024 / 1536 gates: latency kernel 3.3 / 6.1 / 9.0 / 12.0 / 18.0,
     //  4 waves per workgroup 9.5 / 9.6 / 9.7 / 9.8 / 19.6, 8 waves 13.9 / 14.0 / 14.1 / 14.2 / 14.2; tools/shape_bench.py)
     constexpr long long kCoopMax = kCoopWaves > 4 ? 768 : 512;  // rounds of 256 workgroups that still beat 4 waves
+    // FAST mode: the latency kernel (exact arithmetic, valid in either mode) for one round of workgroups only; the
+    // four-wave FAST kernel overtakes it beyond that
+    const long long coop_max = c->arith == TFHE_HIP_ARITH_FAST ? 256 : kCoopMax;
     if (waves == 0)
         waves = MODE == MODE_EXTMUL ? (A.B <= 256 ? 1 : A.B <= 1024 ? 4 : 8)
-                                    : (A.B <= kCoopMax ? kShapeCoop : A.B <= 1024 ? 4 : 8);
+                                    : (A.B <= coop_max ? kShapeCoop : A.B <= 1024 ? 4 : 8);
     if (waves == kShapeCoop && MODE != MODE_EXTMUL) {  // one workgroup per ciphertext (latency shape)
         HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate_coop<MODE == MODE_EXTMUL ? MODE_RAW : MODE>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kCoopLds));
@@ -1570,7 +1857,12 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
         return TFHE_HIP_OK;
     }
     if (waves == kShapeCoop) waves = 1;
-    const size_t lds = kTwLaneEntries * sizeof(c64) + (size_t) waves * kBrLdsPerWave;
+    const bool fast = c->arith == TFHE_HIP_ARITH_FAST;
+    if (fast) {  // the image and the key of the mode (the latency kernel above is exact arithmetic in both modes)
+        A.tw = c->twf;
+        A.bk = c->bkf;
+    }
+    const size_t lds = (fast ? brf::kFastLaneEntries : kTwLaneEntries) * sizeof(c64) + (size_t) waves * kBrLdsPerWave;
     const unsigned grid = (unsigned) ((A.B + waves - 1) / waves);
     auto go = [&](auto kernel) -> int {
         HIPCHK(hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
@@ -1578,7 +1870,11 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
         return TFHE_HIP_OK;
     };
     int r;
-    if (waves == 8) r = go(k_blind_rotate<MODE, 8>);
+    if (fast) {
+        if (waves == 8) r = go(k_blind_rotate<MODE, 8, true>);
+        else if (waves == 4) r = go(k_blind_rotate<MODE, 4, true>);
+        else r = go(k_blind_rotate<MODE, 1, true>);
+    } else if (waves == 8) r = go(k_blind_rotate<MODE, 8>);
     else if (waves == 4) r = go(k_blind_rotate<MODE, 4>);
     else r = go(k_blind_rotate<MODE, 1>);
     if (r) return r;
@@ -1666,6 +1962,18 @@ bool gate_lin(int gate, GateLin &g) {
     }
 }
 
+// FAST mode: (re)derive its key from the exact mode's; called whenever keys were loaded or the mode was selected
+int build_fast_key(tfhe_hip_ctx *c) {
+    if (c->arith != TFHE_HIP_ARITH_FAST || !c->bk) return TFHE_HIP_OK;
+    const long long total = (long long) kLwe * kKpl * 2 * kNh;
+    if (!c->bkf) HIPCHK(hipMalloc((void **) &c->bkf, (size_t) total * sizeof(c64)));
+    hipLaunchKernelGGL(k_bk_to_fast, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream, c->bkf,
+                       (const c64 *) c->bk, total);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TFHE_HIP_OK;
+}
+
 int check_ctx(tfhe_hip_ctx *c, bool need_keys) {
     if (!c) return fail(TFHE_HIP_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
@@ -1731,6 +2039,12 @@ int tfhe_hip_create(tfhe_hip_ctx **out, int device) {
     build_half_twiddles(image.data() + kTwLaneEntries, [&](int i) { return tw[i]; });
     if (e == hipSuccess) e = hipMalloc((void **) &c->tw, image.size() * sizeof(c64));
     if (e == hipSuccess) e = hipMemcpy(c->tw, image.data(), image.size() * sizeof(c64), hipMemcpyHostToDevice);
+    std::vector<c64> fimage(brf::kFastLaneEntries);
+    brf::build_fast_twiddles(fimage.data());
+    if (e == hipSuccess) e = hipMalloc((void **) &c->twf, fimage.size() * sizeof(c64));
+    if (e == hipSuccess) e = hipMemcpy(c->twf, fimage.data(), fimage.size() * sizeof(c64), hipMemcpyHostToDevice);
+    const char *ar = getenv("TFHE_HIP_ARITH");  // default arithmetic of new contexts: "fast" or "exact"
+    if (ar && (!strcmp(ar, "fast") || !strcmp(ar, "FAST") || !strcmp(ar, "1"))) c->arith = TFHE_HIP_ARITH_FAST;
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e != hipSuccess) {
         tfhe_hip_destroy(c);
@@ -1747,6 +2061,8 @@ void tfhe_hip_destroy(tfhe_hip_ctx *c) {
     for (DevBuf *b : {&c->in_a, &c->in_b, &c->in_c, &c->ext1, &c->ext2, &c->outb, &c->misc, &c->abart, &c->ks_part, &c->jobs_br, &c->jobs_ks,
                       &c->jobs_lin}) b->release();
     if (c->tw) (void) hipFree(c->tw);
+    if (c->twf) (void) hipFree(c->twf);
+    if (c->bkf) (void) hipFree(c->bkf);
     if (c->bk) (void) hipFree(c->bk);
     if (c->ks) (void) hipFree(c->ks);
     if (c->kl) (void) hipFree(c->kl);
@@ -1766,6 +2082,16 @@ int tfhe_hip_sync(tfhe_hip_ctx *c) {
     return TFHE_HIP_OK;
 }
 
+int tfhe_hip_set_arithmetic(tfhe_hip_ctx *c, int mode) {
+    if (int r = check_ctx(c, false)) return r;
+    if (mode != TFHE_HIP_ARITH_EXACT && mode != TFHE_HIP_ARITH_FAST) return fail(TFHE_HIP_ERR_ARG, "unknown arithmetic mode");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->arith = mode;
+    if (c->have_keys) return build_fast_key(c);
+    return TFHE_HIP_OK;
+}
+int tfhe_hip_get_arithmetic(tfhe_hip_ctx *c) { return c ? c->arith : TFHE_HIP_ERR_ARG; }
+
 // the coefficient-form bootstrapping key sits in c->misc: transform it, then upload the keyswitch key
 static int keys_from_coef_in_misc(tfhe_hip_ctx *c, const int32_t *ks) {
     const int npoly = kLwe * kKpl * 2;
@@ -1779,6 +2105,7 @@ static int keys_from_coef_in_misc(tfhe_hip_ctx *c, const int32_t *ks) {
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     c->misc.release();
+    if (int r = build_fast_key(c)) return r;
     c->have_keys = true;
     return TFHE_HIP_OK;
 }
@@ -1924,6 +2251,7 @@ int tfhe_hip_load_keys_fft(tfhe_hip_ctx *c, const double *bkfft, const int32_t *
     if (int r = upload_ks(c, ks)) return r;
     HIPCHK(hipStreamSynchronize(c->stream));
     c->misc.release();
+    if (int r = build_fast_key(c)) return r;
     c->have_keys = true;
     return TFHE_HIP_OK;
 }
@@ -2281,9 +2609,15 @@ static int fwd_batch(tfhe_hip_ctx *c, double *spectra, const int32_t *polys, int
     const size_t pb = (size_t) count * kN * sizeof(int32_t), sb = (size_t) count * kNh * sizeof(c64);
     if (int r = h2d(c, c->in_a, polys, pb)) return r;
     HIPCHK(c->outb.reserve(sb));
-    HIPCHK(hipFuncSetAttribute((const void *) k_poly_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
-    hipLaunchKernelGGL(k_poly_fwd, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream,
-                       (const int32_t *) c->in_a.p, (c64 *) c->outb.p, (const c64 *) c->tw, c->ka, (long long) count, torus);
+    if (c->arith == TFHE_HIP_ARITH_FAST) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_poly_fwd_fast, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLdsFast));
+        hipLaunchKernelGGL(k_poly_fwd_fast, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLdsFast, c->stream,
+                           (const int32_t *) c->in_a.p, (c64 *) c->outb.p, (const c64 *) c->twf, c->ka, (long long) count, torus);
+    } else {
+        HIPCHK(hipFuncSetAttribute((const void *) k_poly_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
+        hipLaunchKernelGGL(k_poly_fwd, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream,
+                           (const int32_t *) c->in_a.p, (c64 *) c->outb.p, (const c64 *) c->tw, c->ka, (long long) count, torus);
+    }
     HIPCHK(hipGetLastError());
     return d2h(c, spectra, c->outb.p, sb);
 }
@@ -2300,9 +2634,15 @@ int tfhe_hip_torus_fft_batch(tfhe_hip_ctx *c, int32_t *polys, const double *spec
     const size_t pb = (size_t) count * kN * sizeof(int32_t), sb = (size_t) count * kNh * sizeof(c64);
     if (int r = h2d(c, c->in_a, spectra, sb)) return r;
     HIPCHK(c->outb.reserve(pb));
-    HIPCHK(hipFuncSetAttribute((const void *) k_poly_inv, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
-    hipLaunchKernelGGL(k_poly_inv, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream,
-                       (const c64 *) c->in_a.p, (int32_t *) c->outb.p, (const c64 *) c->tw, c->ka, (long long) count);
+    if (c->arith == TFHE_HIP_ARITH_FAST) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_poly_inv_fast, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLdsFast));
+        hipLaunchKernelGGL(k_poly_inv_fast, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLdsFast, c->stream,
+                           (const c64 *) c->in_a.p, (int32_t *) c->outb.p, (const c64 *) c->twf, c->ka, (long long) count);
+    } else {
+        HIPCHK(hipFuncSetAttribute((const void *) k_poly_inv, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
+        hipLaunchKernelGGL(k_poly_inv, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream,
+                           (const c64 *) c->in_a.p, (int32_t *) c->outb.p, (const c64 *) c->tw, c->ka, (long long) count);
+    }
     HIPCHK(hipGetLastError());
     return d2h(c, polys, c->outb.p, pb);
 }
@@ -2311,9 +2651,15 @@ int tfhe_hip_negacyclic_mul_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const int
     if (int r = check_ctx(c, false)) return r;
     if (count < 0 || (count > 0 && (!d_out || !d_i || !d_t))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
     if (count == 0) return TFHE_HIP_OK;
-    HIPCHK(hipFuncSetAttribute((const void *) k_poly_mul, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
-    hipLaunchKernelGGL(k_poly_mul, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream, d_i, d_t, d_out,
-                       (const c64 *) c->tw, c->ka, (long long) count);
+    if (c->arith == TFHE_HIP_ARITH_FAST) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_poly_mul_fast, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLdsFast));
+        hipLaunchKernelGGL(k_poly_mul_fast, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLdsFast, c->stream, d_i, d_t,
+                           d_out, (const c64 *) c->twf, c->ka, (long long) count);
+    } else {
+        HIPCHK(hipFuncSetAttribute((const void *) k_poly_mul, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
+        hipLaunchKernelGGL(k_poly_mul, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream, d_i, d_t, d_out,
+                           (const c64 *) c->tw, c->ka, (long long) count);
+    }
     HIPCHK(hipGetLastError());
     return TFHE_HIP_OK;
 }

@@ -65,6 +65,7 @@ EXPORTS = [
     "tfhe_hip_encrypt_batch", "tfhe_hip_encrypt_batch_dev", "tfhe_hip_phase_batch", "tfhe_hip_keygen_bk",
     "tfhe_hip_param_set", "tfhe_hip_netlist_create", "tfhe_hip_netlist_run", "tfhe_hip_netlist_is_graph",
     "tfhe_hip_netlist_destroy", "tfhe_hip_keygen_cloud", "tfhe_hip_gate_batch_dev_noalloc",
+    "tfhe_hip_set_arithmetic", "tfhe_hip_get_arithmetic",
 ]
 
 
@@ -172,6 +173,15 @@ class Engine:
     def _chk(self, rc, what):
         if rc != 0:
             raise TfheHipError("%s failed (%d): %s" % (what, rc, self.lib.tfhe_hip_last_error().decode()))
+
+    # ---- arithmetic mode of the FP64 stage: "exact" (bit-identical to the reference) or "fast" ----
+    def set_arithmetic(self, mode):
+        code = {"exact": 0, "fast": 1}[mode] if isinstance(mode, str) else int(mode)
+        self._chk(self.lib.tfhe_hip_set_arithmetic(self.ctx, code), "set_arithmetic")
+
+    @property
+    def arithmetic(self):
+        return "fast" if self.lib.tfhe_hip_get_arithmetic(self.ctx) == 1 else "exact"
 
     # ---- keys ----
     def load_keys_coef(self, bk_coef, ks):
