@@ -2,7 +2,8 @@
 profiles/traffic.json.  Per kernel only the dispatch with the largest grid (the full bench batch) is kept, so the
 single-gate latency launches of bench.py do not blur the per-launch figures.
 
-usage: python tools/summarise_pmc.py r01b r01"""
+usage: python tools/summarise_pmc.py <tag> <round> [mode]     mode (exact | fast): the arithmetic the passes ran with;
+it goes into the output file name and the traffic key that bench.py reads for that mode"""
 import collections
 import csv
 import glob
@@ -12,6 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
+mode = sys.argv[3] if len(sys.argv) > 3 else None
 names = {"k_blind_rotate": "blind_rotate", "k_keyswitch_mfma": "keyswitch_mfma", "k_ks_transpose": "ks_transpose"}
 out = collections.defaultdict(dict)
 for p in ("fetch", "write", "sq1", "sq2", "tcc"):
@@ -28,7 +30,7 @@ for p in ("fetch", "write", "sq1", "sq2", "tcc"):
         for r in mine:
             if int(r["Dispatch_Id"]) == disp:
                 out[short][r["Counter_Name"]] = out[short].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-with open(os.path.join(ROOT, "profiles", "%s_pmc_counters.json" % rnd), "w") as f:
+with open(os.path.join(ROOT, "profiles", "%s_pmc_counters%s.json" % (rnd, "_" + mode if mode else "")), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
 br = out["blind_rotate"]
 if "FETCH_SIZE" in br and "WRITE_SIZE" in br:
@@ -42,6 +44,13 @@ if "FETCH_SIZE" in br and "WRITE_SIZE" in br:
                 "hits these counters include, so this is an upper bound on HBM bytes. Algorithmic bytes per launch: "
                 "16384*7572 B of ciphertext I/O + 61.9 MB of key = 0.19 GB.",
     }
-    with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if mode:   # keep the other mode's entry: one key per mode
+        old = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        old["k_blind_rotate_%s_hbm_bytes_per_launch" % mode] = traffic["k_blind_rotate_hbm_bytes_per_launch"]
+        old["%s_source" % mode] = traffic["source"] + " --arith " + mode + " (round " + rnd + ")"
+        old["%s_FETCH_SIZE_KB" % mode], old["%s_WRITE_SIZE_KB" % mode] = br["FETCH_SIZE"], br["WRITE_SIZE"]
+        traffic = old
+    with open(tpath, "w") as f:
         json.dump(traffic, f, indent=1)
 print(json.dumps(out, indent=1, sort_keys=True))
