@@ -212,10 +212,37 @@ int tfhe_hip_netlist_run(tfhe_hip_netlist *netlist);
 int tfhe_hip_netlist_is_graph(const tfhe_hip_netlist *netlist);
 void tfhe_hip_netlist_destroy(tfhe_hip_netlist *netlist);
 
+/* ---- device group: several GPUs behind one handle ------------------------------------------------
+ * The reference drives one accelerator through one global object (src/include/fpga.h:34) and has no multi-device code.
+ * A group holds one context, stream and host thread per listed device (a device may be listed more than once: that
+ * many contexts share it).  Keys are uploaded once, to the first member, and replicated device to device; a batch is
+ * split into contiguous shards, member i taking gates [i*count/ndev, (i+1)*count/ndev) up to rounding, with no
+ * exchange between the members (gates are independent).  Results equal the single-context call's bit for bit.
+ * tfhe_hip_group_gate_batch returns when every member has finished; errors name the failing member. */
+typedef struct tfhe_hip_group tfhe_hip_group;
+int tfhe_hip_group_create(tfhe_hip_group **out, const int *devices, int ndev);
+void tfhe_hip_group_destroy(tfhe_hip_group *group);
+int tfhe_hip_group_size(const tfhe_hip_group *group);
+tfhe_hip_ctx *tfhe_hip_group_ctx(tfhe_hip_group *group, int member);   /* borrowed; e.g. for the *_dev entry points */
+int tfhe_hip_group_load_keys_coef(tfhe_hip_group *group, const int32_t *bk_coef, const int32_t *ks);
+int tfhe_hip_group_load_keys_fft(tfhe_hip_group *group, const double *bkfft, const int32_t *ks);
+int tfhe_hip_group_set_arithmetic(tfhe_hip_group *group, int mode);
+int tfhe_hip_group_gate_batch(tfhe_hip_group *group, int gate, int32_t *out, const int32_t *a, const int32_t *b,
+                              const int32_t *c, int64_t count);
+
 /* the parameter set this library was built for: out = {lambda, n, N, k, l, Bgbit, ks_t, ks_basebit} */
 void tfhe_hip_param_set(int32_t out[8]);
 
+#define TFHE_HIP_CLIENT_RNG_IS_NOT_CRYPTOGRAPHIC 1
 /* ---- client-side bulk operations (the part that parallelises) ------------------------------
+ * SECURITY NOTE.  Everything in this section (and tfhe_amd/csrc/client_keys.c, whose streams it reproduces) draws keys,
+ * masks and noise from xoshiro256** streams derived from ONE 64-bit seed.  That generator is linear and invertible:
+ * whoever sees a ciphertext's public mask words can rewind to its noise.  These entry points are REPRODUCIBLE FIXTURE
+ * GENERATORS for tests, benchmarks and demos - the same bytes on every machine from a seed - and must not be used to
+ * protect real data.  A deployment generates keys and ciphertexts with the reference's own client functions
+ * (new_random_gate_bootstrapping_secret_keyset, bootsSymEncrypt; tfhe_gate_bootstrapping.cpp:97-159) over a
+ * cryptographic generator and hands the cloud key to tfhe_hip_load_keys_* / tfhe_hip_load_cloud_keyset.
+ *
  * bootsSymEncrypt (tfhe_gate_bootstrapping.cpp:154-159: mu = +-1/8, noise 2^-15) of `count` bits under the secret
  * LWE key (host int32[n], key bits 0/1), and lwePhase (lwe-functions.cpp:63-72; bootsSymDecrypt = phase > 0).
  * The reference's generator (std::default_random_engine + normal_distribution) is not portable, so these reproduce
@@ -232,7 +259,7 @@ int tfhe_hip_encrypt_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, uint64_t seed,
  * as tfhe_client_keygen), transforms it and installs it with the keyswitch key `ks` (host, layout of
  * tfhe_hip_load_keys_coef; NULL keeps the keyswitch key already on the device, see tfhe_hip_keygen_cloud).
  * bk_coef_out (host int32[n][2l][2][N], may be NULL) receives the coefficient form, equal to tfhe_client_keygen's bit
- * for bit.  The secret keys are wiped from device memory before returning. */
+ * for bit.  The secret keys are wiped from device memory before returning, on every exit path. */
 int tfhe_hip_keygen_bk(tfhe_hip_ctx *ctx, uint64_t seed, const int32_t *lwe_key, const int32_t *tlwe_key,
                        const int32_t *ks, int32_t *bk_coef_out);
 /* the whole cloud keyset on the GPU: tfhe_hip_keygen_bk plus lweCreateKeySwitchKey (lwe-keyswitch-functions.cpp:163-215),

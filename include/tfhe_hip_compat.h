@@ -67,9 +67,20 @@ int tfhe_hip_load_cloud_keyset(tfhe_hip_ctx *ctx, const TFheGateBootstrappingClo
 int tfhe_hip_gate_batch_samples(tfhe_hip_ctx *ctx, int gate, LweSample *result, const LweSample *a,
                                 const LweSample *b, const LweSample *c, int32_t count);
 
+/* the same over a device group (tfhe_hip.h): the arrays are split into contiguous shards, one per member */
+int tfhe_hip_group_load_cloud_keyset(tfhe_hip_group *group, const TFheGateBootstrappingCloudKeySet *keyset);
+int tfhe_hip_group_gate_batch_samples(tfhe_hip_group *group, int gate, LweSample *result, const LweSample *a,
+                                      const LweSample *b, const LweSample *c, int32_t count);
+
 /* libtfhe-style batched gates: bootsXXX of src/include/tfhe_gate_bootstrapping_functions.h:14-87 over `count`
- * independent gates.  They use a process-wide default context (GPU $TFHE_HIP_DEVICE, default 0) that uploads `bk` on
- * first use, and - like the reference's die_dramatically (tfhe_gate_bootstrapping.cpp:11-15) - abort on fatal errors. */
+ * independent gates.  They use a process-wide default device group - the GPUs listed in $TFHE_HIP_DEVICES ("0,1,2,3":
+ * each call's gates are sharded over them), else the one GPU $TFHE_HIP_DEVICE (default 0) - and, like the reference's
+ * die_dramatically (tfhe_gate_bootstrapping.cpp:11-15), abort on fatal errors.
+ * KEY CACHING RULE.  The reference copies the whole bkFFT to its device on every call
+ * (lwe-bootstrapping-functions-fft.cpp:112-133); here `bk` is uploaded on first use and kept.  Every call compares the
+ * pointer AND a fingerprint of the key's contents (a hash over a sample of bkFFT and of the keyswitch key, about 0.1 ms)
+ * with what was uploaded, and uploads again when either differs - a keyset freed and another created at the same
+ * address, or bkFFT rewritten in place, is noticed.  tfhe_hip_default_context_reset() drops the cached key explicitly. */
 void bootsNAND_batch(LweSample *result, const LweSample *ca, const LweSample *cb, int32_t count,
                      const TFheGateBootstrappingCloudKeySet *bk);
 void bootsOR_batch(LweSample *result, const LweSample *ca, const LweSample *cb, int32_t count,
@@ -97,10 +108,10 @@ void bootsCOPY_batch(LweSample *result, const LweSample *ca, int32_t count, cons
 void bootsCONSTANT_batch(LweSample *result, int32_t value, int32_t count, const TFheGateBootstrappingCloudKeySet *bk);
 
 /* the reference's device seam with its exact signature (src/include/tfhe.h:42): blind-rotates ONE accumulator on the
- * default context; `bk` must be the bkFFT array of the keyset the default context holds (it is uploaded on first use) */
+ * first GPU of the default group; `bk` is uploaded on first use and whenever its fingerprint changes (rule above) */
 void tfhe_hip_blindRotate_FFT(TLweSample *accum, const TGswSampleFFT *bk, const int32_t *bara, const int32_t n,
                               const TGswParams *bk_params);
-/* releases the default context (optional; for tests and orderly shutdown) */
+/* releases the default group and its cached key (optional; for tests and orderly shutdown) */
 void tfhe_hip_default_context_reset(void);
 
 #ifdef __cplusplus

@@ -85,6 +85,19 @@ void *harness_make_keyset(const double *bkfft, const int32_t *ksflat) {
     return h;
 }
 
+// rewrites the key material of an existing keyset IN PLACE (every pointer keeps its address): what the shim's
+// fingerprint must notice
+void harness_overwrite_keyset(void *p, const double *bkfft, const int32_t *ksflat) {
+    Holder *h = (Holder *) p;
+    for (long r = 0; r < (long) N * T * BASE; r++) {
+        memcpy(h->ks.ks0_raw[r].a, ksflat + r * (n + 1), sizeof(int32_t) * n);
+        h->ks.ks0_raw[r].b = ksflat[r * (n + 1) + n];
+    }
+    for (int i = 0; i < n; i++)
+        for (int q = 0; q < KPL; q++)
+            memcpy(h->bk[i].all_samples[q].a, bkfft + ((size_t) i * KPL + q) * 2 * N, 2 * sizeof(LagrangeHalfCPolynomial));
+}
+
 void harness_free_keyset(void *p) {
     Holder *h = (Holder *) p;
     for (int i = 0; i < n; i++) {

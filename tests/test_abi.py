@@ -64,11 +64,11 @@ def test_product_does_not_touch_the_oracle():
         assert "liboracle" not in text and "tfhe_oracle" not in text and "oracle_lib" not in text, rel
 
 
-def _build_example(tmp_path):
+def _build_example(tmp_path, name="nand_batch"):
     import subprocess
-    exe = str(tmp_path / "nand_batch")
+    exe = str(tmp_path / name)
     subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", "nand_batch.c"), "-L" + os.path.join(ROOT, "tfhe_amd"), "-ltfhe_hip",
+                    os.path.join(ROOT, "examples", name + ".c"), "-L" + os.path.join(ROOT, "tfhe_amd"), "-ltfhe_hip",
                     "-ltfhe_client", "-Wl,-rpath," + os.path.join(ROOT, "tfhe_amd"), "-o", exe], check=True)
     return exe
 
@@ -76,6 +76,7 @@ def _build_example(tmp_path):
 def test_plain_c_example_compiles_and_links(tmp_path):
     """examples/nand_batch.c: a C99 host against include/tfhe_hip.h alone (no C++ in the header, every symbol resolves)"""
     assert os.path.exists(_build_example(tmp_path))
+    assert os.path.exists(_build_example(tmp_path, "group_nand"))
 
 
 @pytest.mark.gpu
@@ -83,3 +84,13 @@ def test_plain_c_example_runs(tmp_path):
     import subprocess
     out = subprocess.run([_build_example(tmp_path), "300"], check=True, capture_output=True, text=True, timeout=120).stdout
     assert "300 NAND gates, 0 wrong" in out
+
+
+@pytest.mark.gpu
+def test_group_c_example_runs(tmp_path):
+    """examples/group_nand.c: a device group of two contexts on GPU 0 (the test box has one GPU); the sharded batch
+    equals the single-context batch bit for bit"""
+    import subprocess
+    out = subprocess.run([_build_example(tmp_path, "group_nand"), "5001", "0", "0"], check=True, capture_output=True,
+                         text=True, timeout=180).stdout
+    assert "5001 NAND gates on 2 member(s), 0 wrong, group == single context: yes" in out

@@ -111,3 +111,30 @@ def test_chunked_struct_path_on_a_large_ragged_batch(keyset, client, keys, engin
     dec, _ = client.decrypt(keys, out)
     assert np.array_equal(dec, 1 - (a & b))
     print("struct-level bootsNAND_batch: %d gates in %.1f ms" % (count, ms))
+
+
+@pytest.mark.gpu
+def test_key_swapped_behind_the_same_pointer_is_noticed(keyset, client, oracle, okeys, keys):
+    """the shim keeps the uploaded key across calls (the reference re-copies bkFFT every call,
+    lwe-bootstrapping-functions-fft.cpp:112-133): a different key behind the SAME keyset pointer must be uploaded again
+    (content fingerprint), not silently ignored"""
+    from tfhe_amd import Gate
+    lib, h = keyset
+    a = np.array([0, 1, 0, 1], np.uint8)
+    b = np.array([0, 0, 1, 1], np.uint8)
+    ca, cb = client.encrypt(keys, a, 61), client.encrypt(keys, b, 62)
+    out = np.zeros((4, PR.n + 1), np.int32)
+    lib.harness_gate(h, int(Gate.NAND), P(out), P(ca), P(cb), None, 4)
+    assert np.array_equal(out[2], oracle.gate(okeys, Gate.NAND, ca[2], cb[2]))
+    keys2 = client.keygen(43)                                    # other secret keys, other cloud keys
+    ok2 = oracle.keys_from_coef(keys2.bk_coef, keys2.ks)
+    try:
+        lib.harness_overwrite_keyset(h, P(np.ascontiguousarray(oracle.bkfft(ok2))), P(np.ascontiguousarray(keys2.ks)))
+        ca2, cb2 = client.encrypt(keys2, a, 63), client.encrypt(keys2, b, 64)
+        lib.harness_gate(h, int(Gate.NAND), P(out), P(ca2), P(cb2), None, 4)
+        assert np.array_equal(client.decrypt(keys2, out)[0], 1 - (a & b))
+        assert np.array_equal(out[1], oracle.gate(ok2, Gate.NAND, ca2[1], cb2[1]))
+    finally:                                                     # the module's keyset fixture goes back to seed 42
+        lib.harness_overwrite_keyset(h, P(np.ascontiguousarray(oracle.bkfft(okeys))), P(np.ascontiguousarray(keys.ks)))
+    lib.harness_gate(h, int(Gate.NAND), P(out), P(ca), P(cb), None, 4)
+    assert np.array_equal(out[2], oracle.gate(okeys, Gate.NAND, ca[2], cb[2]))

@@ -115,3 +115,31 @@ def test_two_ranks_on_one_gpu(tmp_path, engine, client, keys):
     for k in range(W):
         b, _ = client.decrypt(keys, single[k * nl.n_wires + np.array(nl.outputs["out"])])
         assert int(sum(int(v) << i for i, v in enumerate(b))) == int(xs[k] + ys[k])
+
+
+def test_device_group_equals_single_context(engine, client, keys):
+    """tfhe_hip_group_*: the C-level multi-GPU path (one context, stream and host thread per member, keys replicated
+    device to device, contiguous shards).  The test box has one GPU, so the group is {0, 0, 0}: three contexts on it.
+    16,384 + 37 NAND gates and a MUX batch must equal the single-context results bit for bit, in both arithmetic modes"""
+    from tfhe_amd import Group
+    rng = np.random.default_rng(99)
+    count = 16384 + 37
+    bits = rng.integers(0, 2, (3, count)).astype(np.uint8)
+    ct = [client.encrypt(keys, bits[i], 1400 + i) for i in range(3)]
+    g = Group([0, 0, 0])
+    try:
+        assert len(g) == 3
+        g.load_keys_coef(keys.bk_coef, keys.ks)
+        out = g.gate_batch(Gate.NAND, ct[0], ct[1])
+        assert np.array_equal(out, engine.gate_batch(Gate.NAND, ct[0], ct[1]))
+        m = 3000 + 1
+        mux = g.gate_batch(Gate.MUX, ct[0][:m], ct[1][:m], ct[2][:m])
+        assert np.array_equal(mux, engine.gate_batch(Gate.MUX, ct[0][:m], ct[1][:m], ct[2][:m]))
+        assert g.gate_batch(Gate.NAND, ct[0][:0], ct[1][:0]).shape == (0, P.n + 1)
+        two = g.gate_batch(Gate.XOR, ct[0][:2], ct[1][:2])         # fewer gates than members: empty shards
+        assert np.array_equal(two, engine.gate_batch(Gate.XOR, ct[0][:2], ct[1][:2]))
+        g.set_arithmetic("fast")
+        f = g.gate_batch(Gate.NAND, ct[0], ct[1])
+        assert np.array_equal(client.decrypt(keys, f)[0], 1 - (bits[0] & bits[1]))
+    finally:
+        g.close()

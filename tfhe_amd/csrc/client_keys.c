@@ -1,5 +1,10 @@
 /* Client-side key material and ciphertexts for the gate-bootstrapping path (host CPU code, plain C).
  *
+ * NOT CRYPTOGRAPHICALLY SECURE: a reproducible fixture generator for tests, benchmarks and demos.  Keys, masks and
+ * noise come from xoshiro256** streams of one 64-bit seed; the generator is linear and invertible, so a ciphertext's
+ * public mask words give away its noise.  Real deployments generate keys and ciphertexts with the reference's own
+ * client functions over a cryptographic generator (include/tfhe_hip.h, SECURITY NOTE).
+ *
  * The accelerated path only consumes keys and ciphertexts; producing them (key generation, encryption, decryption)
  * is client work that the reference does once on the CPU:
  *   new_random_gate_bootstrapping_secret_keyset   reference src/libtfhe/tfhe_gate_bootstrapping.cpp:97-108

@@ -13,3 +13,9 @@ __attribute__((visibility("hidden"))) int tfhe_hip_internal_gate_batch(tfhe_hip_
                                                                      const int *b, const int *cc, long long count,
                                                                      tfhe_hip_chunk_hook fill, tfhe_hip_chunk_hook drain,
                                                                      void *user);
+
+// runs fn(user, ctx of member i, i, members) on every member's own host thread (tfhe_hip_group) and waits for all;
+// compat_libtfhe.cpp shards libtfhe's LweSample arrays over the members through it
+struct tfhe_hip_group;
+__attribute__((visibility("hidden"))) int tfhe_hip_internal_group_run(
+    tfhe_hip_group *g, int (*fn)(void *user, tfhe_hip_ctx *ctx, int member, int members), void *user);

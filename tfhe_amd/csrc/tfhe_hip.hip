@@ -17,7 +17,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <memory>
 #include <vector>
@@ -2173,6 +2176,27 @@ uint64_t host_splitmix(uint64_t &x) {
 }  // namespace
 extern "C" {
 
+}  // extern "C"
+namespace {
+// zeroes a device region that held secret key material when the enclosing function leaves, whichever way it leaves
+struct DeviceWipe {
+    tfhe_hip_ctx *c;
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool failed = false;
+    void arm(void *ptr, size_t n) { p = ptr; bytes = n; }
+    void now() {
+        if (!p) return;
+        const hipError_t w1 = hipMemsetAsync(p, 0, bytes, c->stream);
+        const hipError_t w2 = hipStreamSynchronize(c->stream);
+        failed = failed || w1 != hipSuccess || w2 != hipSuccess;
+        p = nullptr;
+    }
+    ~DeviceWipe() { now(); }
+};
+}  // namespace
+extern "C" {
+
 int tfhe_hip_keygen_cloud(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key, const int32_t *tlwe_key,
                           int32_t *bk_coef_out, int32_t *ks_out) {
     if (int r = check_ctx(c, false)) return r;
@@ -2189,6 +2213,8 @@ int tfhe_hip_keygen_cloud(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key
     HIPCHK(c->abart.reserve(jump_bytes + (kLwe + kN) * sizeof(int32_t)));
     uint64_t *d_jump = (uint64_t *) c->abart.p;
     int32_t *d_lwe = (int32_t *) ((unsigned char *) c->abart.p + jump_bytes), *d_tlwe = d_lwe + kLwe;
+    DeviceWipe wipe{c};
+    wipe.arm(d_lwe, (kLwe + kN) * sizeof(int32_t));
     HIPCHK(hipMemcpyAsync(d_jump, jump.data(), jump_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_lwe, lwe_key, kLwe * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_tlwe, tlwe_key, kN * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -2199,10 +2225,8 @@ int tfhe_hip_keygen_cloud(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key
     HIPCHK(hipGetLastError());
     if (ks_out) HIPCHK(hipMemcpyAsync(ks_out, c->misc.p, kKsHostElems * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     int r = pack_ks_from_misc(c);
-    const hipError_t w1 = hipMemsetAsync((unsigned char *) c->abart.p + jump_bytes, 0, (kLwe + kN) * sizeof(int32_t), c->stream);
-    const hipError_t w2 = hipStreamSynchronize(c->stream);
-    if (r == TFHE_HIP_OK && (w1 != hipSuccess || w2 != hipSuccess))
-        r = fail(TFHE_HIP_ERR_HIP, "could not wipe the secret keys from device memory");
+    wipe.now();
+    if (r == TFHE_HIP_OK && wipe.failed) r = fail(TFHE_HIP_ERR_HIP, "could not wipe the secret keys from device memory");
     if (r) return r;
     return tfhe_hip_keygen_bk(c, seed, lwe_key, tlwe_key, nullptr, bk_coef_out);
 }
@@ -2218,6 +2242,8 @@ int tfhe_hip_keygen_bk(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key, c
     HIPCHK(c->misc.reserve(coef_bytes));
     HIPCHK(c->abart.reserve((kLwe + kN) * sizeof(int32_t)));
     int32_t *d_lwe = (int32_t *) c->abart.p, *d_tlwe = d_lwe + kLwe;
+    DeviceWipe wipe{c};  // the secret keys do not stay on the device, whatever happens below
+    wipe.arm(d_lwe, (kLwe + kN) * sizeof(int32_t));
     HIPCHK(hipMemcpyAsync(d_lwe, lwe_key, kLwe * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_tlwe, tlwe_key, kN * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_client_bk_draw, dim3((kLwe + 63) / 64), dim3(64), 0, c->stream, seed, (int32_t *) c->misc.p);
@@ -2226,10 +2252,8 @@ int tfhe_hip_keygen_bk(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key, c
     HIPCHK(hipGetLastError());
     if (bk_coef_out) HIPCHK(hipMemcpyAsync(bk_coef_out, c->misc.p, coef_bytes, hipMemcpyDeviceToHost, c->stream));
     const int r = keys_from_coef_in_misc(c, ks);
-    // the secret keys do not stay on the device, whatever the outcome above
-    const hipError_t w1 = hipMemsetAsync(c->abart.p, 0, (kLwe + kN) * sizeof(int32_t), c->stream);
-    const hipError_t w2 = hipStreamSynchronize(c->stream);
-    if (r == TFHE_HIP_OK && (w1 != hipSuccess || w2 != hipSuccess)) {
+    wipe.now();
+    if (r == TFHE_HIP_OK && wipe.failed) {
         c->have_keys = false;
         return fail(TFHE_HIP_ERR_HIP, "could not wipe the secret keys from device memory");
     }
@@ -2722,6 +2746,8 @@ int tfhe_hip_encrypt_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, uint64_t seed, i
     HIPCHK(c->misc.reserve(kLwe * sizeof(int32_t) + (size_t) count));
     int32_t *d_key = (int32_t *) c->misc.p;
     uint8_t *d_bits = (uint8_t *) (d_key + kLwe);
+    DeviceWipe wipe{c};  // the secret key (and the plaintext bits) leave device memory when this call returns
+    wipe.arm(d_key, kLwe * sizeof(int32_t) + (size_t) count);
     HIPCHK(hipMemcpyAsync(d_key, lwe_key, kLwe * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_bits, bits, (size_t) count, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_client_encrypt, dim3((unsigned) ((count + 63) / 64)), dim3(64), 0, c->stream, seed,
@@ -2747,6 +2773,8 @@ int tfhe_hip_phase_batch(tfhe_hip_ctx *c, int32_t *phases, const int32_t *lwe_ke
     const size_t ib = (size_t) count * kCt * sizeof(int32_t);
     if (int r = h2d(c, c->in_a, samples, ib)) return r;
     HIPCHK(c->misc.reserve(kLwe * sizeof(int32_t)));
+    DeviceWipe wipe{c};
+    wipe.arm(c->misc.p, kLwe * sizeof(int32_t));
     HIPCHK(hipMemcpyAsync(c->misc.p, lwe_key, kLwe * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c->outb.reserve((size_t) count * sizeof(int32_t)));
     hipLaunchKernelGGL(k_client_phase, dim3((unsigned) ((count + 3) / 4)), dim3(256), 0, c->stream,
@@ -2961,6 +2989,158 @@ int tfhe_hip_netlist_run(tfhe_hip_netlist *nl) {
 }
 
 int tfhe_hip_netlist_is_graph(const tfhe_hip_netlist *nl) { return nl && nl->exec ? 1 : 0; }
+
+// ---- device group: one context, stream and host thread per GPU (SURVEY.md 8(b) seam row, 8(e)) --------------------------
+// The reference has no multi-device code.  Gates of a batch are independent, so a batch is split into
+// contiguous shards, one per member, with no collective on the data path; keys are uploaded once to the first member
+// and replicated device to device (hipMemcpyPeerAsync: xGMI where the GPUs are linked, staged by the runtime otherwise).
+struct tfhe_hip_group {
+    struct Worker {  // one persistent host thread per member: its thread-local staging buffers and error text live on
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int()> job;
+        bool has_job = false, done = false, quit = false;
+        int rc = 0;
+        std::string err;
+    };
+    std::vector<tfhe_hip_ctx *> ctx;
+    std::vector<std::unique_ptr<Worker>> workers;
+};
+namespace {
+void group_worker_main(tfhe_hip_group::Worker *w) {
+    for (;;) {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+        if (w->quit) return;
+        std::function<int()> job = std::move(w->job);
+        w->has_job = false;
+        lk.unlock();
+        const int rc = job();
+        const std::string err = rc ? g_err : std::string();
+        lk.lock();
+        w->rc = rc;
+        w->err = err;
+        w->done = true;
+        w->cv.notify_all();
+    }
+}
+// runs fn(member index) on every member's thread; first failure (lowest member) is reported to the caller's thread
+int group_run(tfhe_hip_group *g, const std::function<int(int)> &fn) {
+    const int n = (int) g->ctx.size();
+    for (int i = 0; i < n; i++) {
+        tfhe_hip_group::Worker *w = g->workers[i].get();
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->job = [fn, i] { return fn(i); };
+        w->has_job = true;
+        w->done = false;
+        w->cv.notify_all();
+    }
+    int rc = TFHE_HIP_OK;
+    for (int i = 0; i < n; i++) {  // every member finishes before the call returns, whatever the others reported
+        tfhe_hip_group::Worker *w = g->workers[i].get();
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->done; });
+        if (w->rc && rc == TFHE_HIP_OK) rc = fail(w->rc, "group member " + std::to_string(i) + ": " + w->err);
+    }
+    return rc;
+}
+void shard(long long count, int i, int n, long long &lo, long long &hi) {  // contiguous blocks, sizes differ by at most one
+    const long long base = count / n, rem = count % n;
+    lo = i * base + std::min<long long>(i, rem);
+    hi = lo + base + (i < rem ? 1 : 0);
+}
+// device-to-device replica of member 0's keys (after tfhe_hip_load_keys_* on member 0)
+int replicate_keys(tfhe_hip_ctx *dst, const tfhe_hip_ctx *src) {
+    HIPCHK(hipSetDevice(dst->device));
+    dst->have_keys = false;
+    if (!dst->bk) HIPCHK(hipMalloc((void **) &dst->bk, kBkBytes));
+    if (!dst->ks) HIPCHK(hipMalloc((void **) &dst->ks, kKsDevBytes));
+    const size_t kl_bytes = (size_t) kN * 4 * kKsQ * 32;
+    if (!dst->kl) HIPCHK(hipMalloc((void **) &dst->kl, kl_bytes));
+    HIPCHK(hipMemcpyPeerAsync(dst->bk, dst->device, src->bk, src->device, kBkBytes, dst->stream));
+    HIPCHK(hipMemcpyPeerAsync(dst->ks, dst->device, src->ks, src->device, kKsDevBytes, dst->stream));
+    HIPCHK(hipMemcpyPeerAsync(dst->kl, dst->device, src->kl, src->device, kl_bytes, dst->stream));
+    HIPCHK(hipStreamSynchronize(dst->stream));
+    if (int r = build_fast_key(dst)) return r;
+    dst->have_keys = true;
+    return TFHE_HIP_OK;
+}
+}  // namespace
+
+int tfhe_hip_group_create(tfhe_hip_group **out, const int *devices, int ndev) {
+    if (!out) return fail(TFHE_HIP_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    if (!devices || ndev < 1 || ndev > 64) return fail(TFHE_HIP_ERR_ARG, "bad device list");
+    std::unique_ptr<tfhe_hip_group, void (*)(tfhe_hip_group *)> g(new tfhe_hip_group, tfhe_hip_group_destroy);
+    for (int i = 0; i < ndev; i++) {
+        tfhe_hip_ctx *c = nullptr;
+        if (int r = tfhe_hip_create(&c, devices[i])) return r;
+        g->ctx.push_back(c);
+    }
+    for (int i = 0; i < ndev; i++) {
+        g->workers.emplace_back(new tfhe_hip_group::Worker);
+        g->workers.back()->th = std::thread(group_worker_main, g->workers.back().get());
+    }
+    *out = g.release();
+    return TFHE_HIP_OK;
+}
+void tfhe_hip_group_destroy(tfhe_hip_group *g) {
+    if (!g) return;
+    for (auto &w : g->workers) {
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->quit = true;
+            w->cv.notify_all();
+        }
+        if (w->th.joinable()) w->th.join();
+    }
+    for (tfhe_hip_ctx *c : g->ctx) tfhe_hip_destroy(c);
+    delete g;
+}
+int tfhe_hip_group_size(const tfhe_hip_group *g) { return g ? (int) g->ctx.size() : 0; }
+tfhe_hip_ctx *tfhe_hip_group_ctx(tfhe_hip_group *g, int i) {
+    return g && i >= 0 && i < (int) g->ctx.size() ? g->ctx[i] : nullptr;
+}
+static int group_replicate(tfhe_hip_group *g) {
+    return group_run(g, [g](int i) { return i == 0 ? TFHE_HIP_OK : replicate_keys(g->ctx[i], g->ctx[0]); });
+}
+int tfhe_hip_group_load_keys_coef(tfhe_hip_group *g, const int32_t *bk_coef, const int32_t *ks) {
+    if (!g) return fail(TFHE_HIP_ERR_ARG, "null group");
+    if (int r = tfhe_hip_load_keys_coef(g->ctx[0], bk_coef, ks)) return r;
+    return group_replicate(g);
+}
+int tfhe_hip_group_load_keys_fft(tfhe_hip_group *g, const double *bkfft, const int32_t *ks) {
+    if (!g) return fail(TFHE_HIP_ERR_ARG, "null group");
+    if (int r = tfhe_hip_load_keys_fft(g->ctx[0], bkfft, ks)) return r;
+    return group_replicate(g);
+}
+int tfhe_hip_group_set_arithmetic(tfhe_hip_group *g, int mode) {
+    if (!g) return fail(TFHE_HIP_ERR_ARG, "null group");
+    return group_run(g, [g, mode](int i) { return tfhe_hip_set_arithmetic(g->ctx[i], mode); });
+}
+int tfhe_hip_group_gate_batch(tfhe_hip_group *g, int gate, int32_t *out, const int32_t *a, const int32_t *b,
+                              const int32_t *c, int64_t count) {
+    if (!g) return fail(TFHE_HIP_ERR_ARG, "null group");
+    if (count < 0 || (count > 0 && !out)) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    const int n = (int) g->ctx.size();
+    return group_run(g, [=](int i) -> int {
+        long long lo, hi;
+        shard(count, i, n, lo, hi);
+        if (hi == lo) return TFHE_HIP_OK;
+        const size_t o = (size_t) lo * kCt;
+        return tfhe_hip_gate_batch(g->ctx[i], gate, out + o, a ? a + o : nullptr, b ? b + o : nullptr, c ? c + o : nullptr,
+                                   hi - lo);
+    });
+}
+}  // extern "C"
+int tfhe_hip_internal_group_run(tfhe_hip_group *g, int (*fn)(void *user, tfhe_hip_ctx *ctx, int member, int members),
+                                void *user) {
+    if (!g || !fn) return fail(TFHE_HIP_ERR_ARG, "null group");
+    const int n = (int) g->ctx.size();
+    return group_run(g, [=](int i) { return fn(user, g->ctx[i], i, n); });
+}
+extern "C" {
 
 // device-memory helpers so that C callers of the *_dev entry points need no HIP of their own
 int tfhe_hip_dev_alloc(tfhe_hip_ctx *c, size_t bytes, void **out) {

@@ -66,6 +66,9 @@ EXPORTS = [
     "tfhe_hip_param_set", "tfhe_hip_netlist_create", "tfhe_hip_netlist_run", "tfhe_hip_netlist_is_graph",
     "tfhe_hip_netlist_destroy", "tfhe_hip_keygen_cloud", "tfhe_hip_gate_batch_dev_noalloc",
     "tfhe_hip_set_arithmetic", "tfhe_hip_get_arithmetic",
+    "tfhe_hip_group_create", "tfhe_hip_group_destroy", "tfhe_hip_group_size", "tfhe_hip_group_ctx",
+    "tfhe_hip_group_load_keys_coef", "tfhe_hip_group_load_keys_fft", "tfhe_hip_group_set_arithmetic",
+    "tfhe_hip_group_gate_batch",
 ]
 
 
@@ -137,6 +140,61 @@ class CompiledNetlist:
     def close(self):
         if getattr(self, "handle", None):
             self.lib.tfhe_hip_netlist_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Group:
+    """tfhe_hip_group: several GPUs behind one handle (one context, stream and host thread per listed device); keys
+    uploaded once and replicated device to device, batches split into contiguous shards"""
+
+    def __init__(self, devices, params=PARAMS):
+        self.params = params
+        self.lib = load_library(params)
+        self.lib.tfhe_hip_group_destroy.restype = None
+        self.lib.tfhe_hip_group_destroy.argtypes = [ctypes.c_void_p]
+        devs = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        rc = self.lib.tfhe_hip_group_create(ctypes.byref(h), devs, len(devices))
+        if rc != 0:
+            raise TfheHipError("tfhe_hip_group_create(%r): %s" % (list(devices), self.lib.tfhe_hip_last_error().decode()))
+        self.handle = h
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise TfheHipError("%s failed (%d): %s" % (what, rc, self.lib.tfhe_hip_last_error().decode()))
+
+    def __len__(self):
+        return self.lib.tfhe_hip_group_size(self.handle)
+
+    def load_keys_coef(self, bk_coef, ks):
+        P = self.params
+        bk = _i32(bk_coef, (P.n, P.kpl, 2, P.N))
+        k = _i32(ks, (P.N, P.ks_t, P.ks_base, P.n + 1))
+        self._chk(self.lib.tfhe_hip_group_load_keys_coef(self.handle, _p(bk), _p(k)), "group_load_keys_coef")
+
+    def set_arithmetic(self, mode):
+        code = {"exact": 0, "fast": 1}[mode] if isinstance(mode, str) else int(mode)
+        self._chk(self.lib.tfhe_hip_group_set_arithmetic(self.handle, code), "group_set_arithmetic")
+
+    def gate_batch(self, gate, a=None, b=None, c=None, count=None):
+        P = self.params
+        a, b, c = (_i32(x, (P.n + 1,)) for x in (a, b, c))
+        if count is None:
+            count = a.shape[0]
+        out = np.empty((count, P.n + 1), dtype=np.int32)
+        self._chk(self.lib.tfhe_hip_group_gate_batch(self.handle, int(gate), _p(out), _p(a), _p(b), _p(c),
+                                                     ctypes.c_int64(count)), "group_gate_batch")
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.tfhe_hip_group_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -231,6 +289,9 @@ class Engine:
         return out
 
     # ---- device-resident (torch tensors or raw device pointers) ----
+    # STREAM CONTRACT: these launch on the context's own non-blocking stream (self.stream()), not on torch's current
+    # stream.  Inputs written by torch must have landed first (torch.cuda.current_stream().synchronize()), and
+    # self.sync() must return before torch reads the outputs.
     @staticmethod
     def _dptr(t):
         if t is None:
