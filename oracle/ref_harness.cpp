@@ -406,3 +406,94 @@ int32_t ref_export_params(const char *path) {
     return 0;
 }
 }  // extern "C"
+
+// ---- the 80-bit parameter set (n = 500, l = 2, Bgbit = 10; tfhe_gate_bootstrapping.cpp:23-48), stage by stage ------
+// The fork's composed hot path hard-codes the default set (Value_n, Value_l, Value_Bgbit: tfhe_core.h:13-24), but these
+// stages of the reference take their parameters at run time: lweKeySwitch (lwe-keyswitch-functions.cpp:114-129,228-238),
+// the generic gadget decomposition Torus32PolynomialDecompH_old (tgsw-functions.cpp:277-293), tGswToFFTConvert
+// (tgsw-fft-operations.cpp:52-57) and the transform-domain pieces of the external product (IntPolynomial_ifft,
+// tLweFFTClear / tLweFFTAddMulRTo / tLweFromFFTConvert: k = 1 and N = 1024 in both sets).  The external product below is
+// tGswFFTExternMulToTLwe (tgsw-fft-operations.cpp:92-120) line for line with the generic decomposition in place of the
+// hard-wired one - every arithmetic operation is the reference's.
+extern "C" void Torus32PolynomialDecompH_old(IntPolynomial *result, const TorusPolynomial *sample, const TGswParams *params);
+static TFheGateBootstrappingParameterSet *g_p80 = nullptr;
+static void ensure80() {
+    if (!g_p80) g_p80 = new_default_gate_bootstrapping_parameters(80);
+}
+extern "C" {
+void ref80_get_sizes(int32_t *out) {  // n, N, k, l, Bgbit, kpl, t, basebit
+    ensure80();
+    out[0] = g_p80->in_out_params->n;
+    out[1] = g_p80->tgsw_params->tlwe_params->N;
+    out[2] = g_p80->tgsw_params->tlwe_params->k;
+    out[3] = g_p80->tgsw_params->l;
+    out[4] = g_p80->tgsw_params->Bgbit;
+    out[5] = g_p80->tgsw_params->kpl;
+    out[6] = g_p80->ks_t;
+    out[7] = g_p80->ks_basebit;
+}
+void ref80_decomp(int32_t *out /*[l][N]*/, const int32_t *poly /*N*/) {
+    ensure80();
+    const TGswParams *gp = g_p80->tgsw_params;
+    IntPolynomial *r = new_IntPolynomial_array(gp->l);
+    TorusPolynomial *p = new_TorusPolynomial();
+    memcpy(p->coefsT, poly, sizeof(int32_t) * N_);
+    Torus32PolynomialDecompH_old(r, p, gp);
+    for (int q = 0; q < gp->l; q++) memcpy(out + q * N_, r[q].coefs, sizeof(int32_t) * N_);
+    delete_TorusPolynomial(p); delete_IntPolynomial_array(gp->l, r);
+}
+// count keyswitches LWE_N -> LWE_500 with the key ks[N][t][base][n80+1]
+void ref80_keyswitch(int32_t *out /*[count][n80+1]*/, const int32_t *in /*[count][N+1]*/, const int32_t *ks, int32_t count) {
+    ensure80();
+    const LweParams *op = g_p80->in_out_params;
+    const int32_t n80 = op->n;
+    LweKeySwitchKey *k = new_LweKeySwitchKey(N_, g_p80->ks_t, g_p80->ks_basebit, op);
+    for (int i = 0; i < N_; i++)
+        for (int j = 0; j < t_; j++)
+            for (int d = 0; d < base_; d++)
+                to_sample(&k->ks[i][j][d], ks + (((size_t) i * t_ + j) * base_ + d) * (n80 + 1), n80);
+    LweSample *u = new_LweSample(&g_p80->tgsw_params->tlwe_params->extracted_lweparams);
+    LweSample *r = new_LweSample(op);
+    for (int c = 0; c < count; c++) {
+        to_sample(u, in + (size_t) c * (N_ + 1), N_);
+        lweKeySwitch(r, k, u);
+        from_sample(out + (size_t) c * (n80 + 1), r, n80);
+    }
+    delete_LweSample(r); delete_LweSample(u); delete_LweKeySwitchKey(k);
+}
+// one TGSW sample, coefficient domain tgsw[kpl][2][N] -> bkfft_out[kpl][2][N/2][2] (tGswToFFTConvert), and
+// acc[2][N] <- tgsw (*) acc
+void ref80_extern_mul(int32_t *acc /*[2][N] in/out*/, double *bkfft_out /*may be null*/, const int32_t *tgsw) {
+    ensure80();
+    const TGswParams *gp = g_p80->tgsw_params;
+    const TLweParams *tp = gp->tlwe_params;
+    const int32_t k = tp->k, l = gp->l, kpl = gp->kpl;
+    TGswSample *s = new_TGswSample(gp);
+    for (int p = 0; p < kpl; p++) {
+        for (int c = 0; c < 2; c++) memcpy(s->all_sample[p].a[c].coefsT, tgsw + ((size_t) p * 2 + c) * N_, sizeof(int32_t) * N_);
+        s->all_sample[p].current_variance = 0.;
+    }
+    TGswSampleFFT *gsw = new_TGswSampleFFT(gp);
+    tGswToFFTConvert(gsw, s, gp);
+    if (bkfft_out)
+        for (int p = 0; p < kpl; p++)
+            for (int c = 0; c < 2; c++)
+                memcpy(bkfft_out + ((size_t) p * 2 + c) * N_, gsw->all_samples[p].a[c].coefsC, sizeof(double) * N_);
+    TLweSample *accum = new_TLweSample(tp);
+    to_tlwe(accum, acc);
+    // tgsw-fft-operations.cpp:92-120
+    IntPolynomial *deca = new_IntPolynomial_array(kpl);
+    LagrangeHalfCPolynomial *decaFFT = new_LagrangeHalfCPolynomial_array(kpl);
+    TLweSampleFFT *tmpa = new_TLweSampleFFT(tp);
+    for (int32_t i = 0; i <= k; i++) Torus32PolynomialDecompH_old(deca + i * l, accum->a + i, gp);   // :103-105, generic form
+    for (int32_t p = 0; p < kpl; p++) IntPolynomial_ifft(&decaFFT[p], &deca[p]);                     // :106-108
+    tLweFFTClear(tmpa);                                                                              // :110
+    for (int32_t p = 0; p < kpl; p++) tLweFFTAddMulRTo(tmpa, decaFFT + p, gsw->all_samples + p);     // :112-114
+    tLweFromFFTConvert(accum, tmpa);                                                                 // :115
+    delete_TLweSampleFFT(tmpa);
+    delete_LagrangeHalfCPolynomial_array(kpl, decaFFT);
+    delete_IntPolynomial_array(kpl, deca);
+    from_tlwe(acc, accum);
+    delete_TLweSample(accum); delete_TGswSampleFFT(gsw); delete_TGswSample(s);
+}
+}  // extern "C"

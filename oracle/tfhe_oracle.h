@@ -9,8 +9,10 @@ extern "C" {
 #endif
 
 /* liboracle.so: the default 128-bit set (tfhe_gate_bootstrapping.cpp:51-75; the one this reference hard-codes in
- * src/include/tfhe_core.h:13-24).  liboracle_80.so (-DORC_LAMBDA=80): the 80-bit set of :23-48 - PARITY UNPINNED,
- * the reference's own hot path cannot run that set (its n, l, Bgbit are compile-time constants). */
+ * src/include/tfhe_core.h:13-24).  liboracle_80.so (-DORC_LAMBDA=80): the 80-bit set of :23-48 - PINNED PER STAGE
+ * (keyswitch, gadget decomposition, key conversion, external product: tests/golden/stages_80.npz holds the reference's
+ * own outputs of its run-time-parameterised stage functions); the COMPOSED bootstrap of that set is unpinned, because
+ * the reference's own composed hot path cannot run it (its n, l, Bgbit are compile-time constants). */
 #ifndef ORC_LAMBDA
 #define ORC_LAMBDA 128
 #endif

@@ -29,8 +29,9 @@ def i32(a):
 
 class Oracle:
     def __init__(self, params=None):
-        """params: a tfhe_amd.ParamSet; None = the default 128-bit set.  The 80-bit oracle is PARITY UNPINNED (the
-        reference hard-codes the default set in its hot path, src/include/tfhe_core.h:13-24)."""
+        """params: a tfhe_amd.ParamSet; None = the default 128-bit set.  The 80-bit oracle is pinned per stage against
+        the reference (tests/golden/stages_80.npz); its composed bootstrap is unpinned (the reference hard-codes the
+        default set in its composed hot path, src/include/tfhe_core.h:13-24)."""
         self.n, self.kpl, self.l = (630, 6, 3) if params is None else (params.n, params.kpl, params.l)
         so = ORACLE_SO if params is None or params.lam == 128 else ORACLE_SO.replace(".so", "%s.so" % params.suffix)
         self.lib = ctypes.CDLL(so)

@@ -1,11 +1,17 @@
 """The 80-bit parameter set (n = 500, l = 2, Bgbit = 10; tfhe_gate_bootstrapping.cpp:23-48), SURVEY 8(f) N4.
 
-PARITY UNPINNED against the reference: this fork hard-codes the default set's n, l, Bgbit as compile-time constants in
-its hot path (src/include/tfhe_core.h:13-24, used in tgsw-functions.cpp, lwe-bootstrapping-functions-fft.cpp), so the
-reference cannot run this set and holds no vectors for it.  What is checked instead:
-  * the CPU restatement built for this set (oracle/liboracle_80.so: the same source as the pinned 128-bit oracle, other
-    constants) against an independent numpy statement of the gadget decomposition, and through decryption of its gates;
-  * the GPU library built for this set (libtfhe_hip_80.so) against that oracle, bit for bit, in every launch shape."""
+PINNED PER STAGE, composed bootstrap unpinned.  This fork hard-codes the default set's n, l, Bgbit as compile-time
+constants in its composed hot path (src/include/tfhe_core.h:13-24, used in tGswTorus32PolynomialDecompH and
+lwe-bootstrapping-functions-fft.cpp), so the reference cannot run a whole bootstrap of this set.  Its stages, however,
+take their parameters at run time: lweKeySwitch, the generic gadget decomposition Torus32PolynomialDecompH_old,
+tGswToFFTConvert and the transform-domain pieces of tGswFFTExternMulToTLwe.  tests/golden/stages_80.npz holds inputs
+and the reference's own outputs of those (oracle/gen_golden_80.py, ref80_* of oracle/ref_harness.cpp); the oracle built
+for this set (oracle/liboracle_80.so) and the GPU library (libtfhe_hip_80.so) must replay them bit for bit.  On top:
+  * the oracle against an independent numpy statement of the gadget decomposition, and through decryption of its gates;
+  * the GPU library against that oracle, bit for bit, in every launch shape (the composed bootstrap: same CMux code as
+    the pinned stages, iterated)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -191,3 +197,34 @@ def test_wire_formats_of_the_80_bit_library(keys80, client80, tmp_path):
     blob = wire.write_samples(cts, params=P)
     assert len(blob) == 3 * wire.sample_bytes(P) == 3 * (4 + 4 * 501 + 8)
     assert np.array_equal(wire.read_samples(blob, params=P)[0], cts)
+
+
+# ---- pinned against the reference, stage by stage (tests/golden/stages_80.npz) -----------------------------------------
+@pytest.fixture(scope="module")
+def stages80():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "stages_80.npz"))
+
+
+def test_oracle_replays_the_reference_stages(stages80, oracle80, okeys80):
+    g = stages80
+    for i in range(g["decomp_in"].shape[0]):     # Torus32PolynomialDecompH_old, l = 2, Bgbit = 10
+        dec = oracle80.decomp(g["decomp_in"][i])
+        assert np.array_equal(dec, g["decomp_out"][i])
+        # the reconstruction check of src/test/test-decomp-tgsw.cpp:72-79 (written there for Bgbit = 10)
+        rec = (dec[0].astype(np.int64) << 22) + (dec[1].astype(np.int64) << 12)
+        err = (rec - g["decomp_in"][i].astype(np.int64) + 2**31) % 2**32 - 2**31
+        assert np.abs(err).max() < 2**12
+    for i in range(0, g["ks_in"].shape[0], 7):   # lweKeySwitch at n = 500
+        assert np.array_equal(oracle80.keyswitch(okeys80, g["ks_in"][i]), g["ks_out"][i]), i
+    bk = oracle80.bkfft(okeys80)
+    for r, i in enumerate(g["extmul_index"]):    # tGswToFFTConvert, tGswFFTExternMulToTLwe
+        assert np.array_equal(bk[i], g["bkfft_rows"][r]), i
+        assert np.array_equal(oracle80.extern_mul(okeys80, g["extmul_acc"][r], int(i)), g["extmul_out"][r]), i
+
+
+@pytest.mark.gpu
+def test_gpu_replays_the_reference_stages(stages80, engine80):
+    g = stages80
+    assert np.array_equal(engine80.keyswitch_batch(g["ks_in"]), g["ks_out"])
+    assert np.array_equal(engine80.get_bkfft()[g["extmul_index"]], g["bkfft_rows"])
+    assert np.array_equal(engine80.extern_mul_batch(g["extmul_acc"], g["extmul_index"]), g["extmul_out"])
