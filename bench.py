@@ -71,16 +71,70 @@ def cpu_baseline(keys, ca, cb, expect_bits, client, params=None):
                       % (count, per_thread, threads, dt, 1e3 * dt * threads / count)}, out
 
 
+FLOP_PER_FFT_PRODUCT = 3 * 26112.0 + 4096.0   # two forward + one inverse transform, 512 complex multiplications
+
+
+def _roofline(kernel, flop_per_launch, launch_ms, detail):
+    achieved = flop_per_launch / (launch_ms * 1e-3) / 1e12
+    return {"bound": "fp64_valu", "bound_detail": detail, "kernel": kernel, "achieved": achieved,
+            "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+            "traffic": None, "flop_per_launch": flop_per_launch, "launch_ms": launch_ms}
+
+
+def _cpu_threads():
+    share = int(os.environ.get("TFHE_BENCH_CPU_THREADS", "0")) or int(os.environ.get("OMP_NUM_THREADS", "0")) or 1 << 30
+    return max(1, min(len(os.sched_getaffinity(0)), share, 256))
+
+
+def _ref_lib(keys=None):
+    """the reference build, if it travelled here (oracle/_ref), with the keys installed"""
+    import ctypes
+    from tests.oracle_lib import REF_SO, P
+    if not os.path.exists(REF_SO):
+        return None
+    try:
+        ref = ctypes.CDLL(REF_SO)
+    except OSError:
+        return None
+    if keys is not None:
+        ref.ref_set_keys(P(keys.lwe_key), P(keys.tlwe_key), P(keys.bk_coef), P(keys.ks))
+    return ref
+
+
+def cpu_gates(keys, gate, a, b, c, threads):
+    """`count` gates of one kind on the host cores: the reference itself if present, else the oracle port"""
+    import ctypes
+    from tests.oracle_lib import Oracle, P
+    count = a.shape[0]
+    out = np.zeros_like(a)
+    ref = _ref_lib(keys)
+    t0 = time.perf_counter()
+    if ref is not None:
+        ref.ref_gate_batch(int(gate), P(out), P(a), P(b), None if c is None else P(c), ctypes.c_longlong(count),
+                           ctypes.c_int32(threads))
+        kind = "reference"
+    else:
+        orc = Oracle()
+        out = orc.gate_batch(orc.keys_from_coef(keys.bk_coef, keys.ks), int(gate), a, b, c, nthreads=threads)
+        kind = "port"
+    return out, time.perf_counter() - t0, kind
+
+
 def side_bench(args, torch, dev, rank, world):
     """BASELINE configs[4]: bootsMUX batch (two bootstraps + one keyswitch per gate) and the batched negacyclic
     IntPolynomial x TorusPolynomial FFT product at N = 1024 (torusPolynomialMultFFT, reference polynomials.cpp:241).
     N = 2048 (--workload fft2048) is composed of four N = 1024 products: the reference's transform is compiled for
-    N = 1024 only (tfhe_core.h:14), its naive product is the oracle there."""
+    N = 1024 only (tfhe_core.h:14), its naive product is the oracle there.  configs[3]: --workload adder | comparator.
+    Every line carries roofline (HIP events on the engine's stream) and cpu_baseline like the headline."""
     from tfhe_amd import Client, Engine, Gate, PARAMS as PR
     assert world == 1, "side benches are single-GPU"
     eng = Engine(0)
-    if args.workload == "adder":
-        return adder_bench(args, torch, dev, eng)
+    mode = "exact" if args.arith == "exact" else "fast"
+    eng.set_arithmetic(mode)
+    if args.workload in ("adder", "comparator"):
+        return netlist_bench(args, torch, dev, eng, mode)
+    threads = _cpu_threads()
+    cpu = None
     if args.workload == "mux":
         client = Client()
         keys = client.keygen(42)
@@ -88,52 +142,106 @@ def side_bench(args, torch, dev, rank, world):
         B = args.batch
         rng = np.random.default_rng(5)
         bits = [rng.integers(0, 2, B).astype(np.uint8) for _ in range(3)]
-        d = [torch.from_numpy(client.encrypt(keys, b, seed=50 + i)).to(dev) for i, b in enumerate(bits)]
+        cts = [client.encrypt(keys, b, seed=50 + i) for i, b in enumerate(bits)]
+        d = [torch.from_numpy(c).to(dev) for c in cts]
         d_out = torch.empty((B, PR.n + 1), dtype=torch.int32, device=dev)
         run = lambda: eng.gate_batch_dev(Gate.MUX, d_out, d[0], d[1], d[2], count=B)  # noqa: E731
         unit, per_step, name = "gates/s", B, "bootsMUX gates/sec (2 bootstraps + 1 keyswitch each)"
+        flop = 2 * FLOP_PER_BOOTSTRAP * B
+        kernel = "k_blind_rotate<%s> x 2" % mode
     else:
         B = 1 << 16
         n = PR.N if args.workload == "fft" else 2 * PR.N
         rng = np.random.default_rng(6)
-        a = torch.from_numpy(rng.integers(-2 * n, 2 * n, (B, n)).astype(np.int32)).to(dev)
-        b = torch.from_numpy(rng.integers(-2**31, 2**31, (B, n)).astype(np.int32)).to(dev)
+        ha = rng.integers(-2 * n, 2 * n, (B, n)).astype(np.int32)   # src/test/test-multiplication.cpp:41-44
+        hb = rng.integers(-2**31, 2**31, (B, n)).astype(np.int32)
+        a, b = torch.from_numpy(ha).to(dev), torch.from_numpy(hb).to(dev)
         d_out = torch.empty((B, n), dtype=torch.int32, device=dev)
         if args.workload == "fft":
             run = lambda: eng.negacyclic_mul_dev(d_out, a, b, B)  # noqa: E731
+            flop, kernel = FLOP_PER_FFT_PRODUCT * B, "k_poly_mul%s" % ("_fast" if mode == "fast" else "")
         else:   # N = 2048: four N = 1024 products per product (even/odd split), no reference transform exists
             run = lambda: eng.negacyclic_mul2048_dev(d_out, a, b, B)  # noqa: E731
+            flop, kernel = 4 * FLOP_PER_FFT_PRODUCT * B, "k_split2048 + k_poly_mul%s + k_combine2048" % ("_fast" if mode == "fast" else "")
         unit, per_step, name = "products/s", B, "negacyclic IntPolynomial x TorusPolynomial FFT products/sec, N=%d" % n
     for _ in range(args.warmup):
         run()
     eng.sync()
+    kms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
+        kms.append(eng.last_kernel_ms()[0])    # HIP events around the call's FP64 kernels, on the engine's stream
     eng.sync()
     dt = time.perf_counter() - t0
+    got = d_out.cpu().numpy()
+    if not args.no_cpu_baseline:
+        from concurrent.futures import ThreadPoolExecutor
+        from tests.oracle_lib import Oracle, P
+        if args.workload == "mux":
+            cnt = threads * 6
+            out, cdt, kind = cpu_gates(keys, Gate.MUX, cts[0][:cnt], cts[1][:cnt], cts[2][:cnt], threads)
+            if mode == "exact":
+                assert np.array_equal(out, got[:cnt]), "GPU ciphertexts differ from the CPU path's"
+            assert np.array_equal(client.decrypt(keys, out)[0], client.decrypt(keys, got[:cnt])[0])
+            cpu = {"value": cnt / cdt, "unit": unit, "cores": threads, "kind": kind, "host_cores_available": len(os.sched_getaffinity(0)),
+                   "sample": "%d bootsMUX gates, 6 per thread on %d threads, %.1f s wall" % (cnt, threads, cdt)}
+        else:
+            orc = Oracle()
+            ref = _ref_lib() if args.workload == "fft" else None
+            per = 2000 if args.workload == "fft" else 60
+            cnt = threads * per
+            out = np.zeros((cnt, got.shape[1]), np.int32)
+
+            def work(t):
+                for i in range(t * per, (t + 1) * per):
+                    if args.workload == "fft2048":   # the reference's exact product (multiplication.cpp:31-43), N as argument
+                        orc.lib.oracle_mulNaive(P(out[i]), P(ha[i]), P(hb[i]), ctypes_i32(got.shape[1]))
+                    elif ref is not None:
+                        ref.ref_mul_fft(P(out[i]), P(ha[i]), P(hb[i]))
+                    else:
+                        orc.lib.oracle_mulFFT(P(out[i]), P(ha[i]), P(hb[i]))
+            import ctypes
+            ctypes_i32 = ctypes.c_int32
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(threads) as ex:
+                list(ex.map(work, range(threads)))
+            cdt = time.perf_counter() - t1
+            diff = np.abs((got[:cnt].astype(np.int64) - out.astype(np.int64) + 2**31) % 2**32 - 2**31).max()
+            assert diff <= (2 if args.workload == "fft2048" else (0 if mode == "exact" else 1)), diff
+            cpu = {"value": cnt / cdt, "unit": unit, "cores": threads, "host_cores_available": len(os.sched_getaffinity(0)),
+                   "kind": "reference" if ref is not None else "port",
+                   "sample": "%d products on %d threads, %.1f s wall; %s; GPU results within %d LSB of them" % (
+                       cnt, threads, cdt, "torusPolynomialMultFFT (polynomials.cpp:241)" if args.workload == "fft" else
+                       "exact schoolbook product torusPolynomialMultNaive_aux (multiplication.cpp:31-43): the reference "
+                       "has no N = 2048 transform", int(diff))}
     if args.workload == "mux":
-        dec, _ = client.decrypt(keys, d_out.cpu().numpy())
+        dec, _ = client.decrypt(keys, got)
         assert np.array_equal(dec, np.where(bits[0] == 1, bits[1], bits[2])), "MUX outputs decrypt wrongly"
     print(json.dumps({"metric": name, "value": per_step * args.steps / dt, "unit": unit, "n_gpus": 1,
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                      "higher_is_better": True, "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": args.workload, "batch": per_step}}), flush=True)
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": "%s, %s arithmetic (BASELINE configs[4])" % (args.workload, mode.upper()),
+                                 "arithmetic": mode, "batch": per_step},
+                      "roofline": _roofline(kernel, flop, float(np.mean(kms)),
+                                            "FP64 vector ALUs; launch = the FP64 kernels of one call (HIP events on the engine's stream)"),
+                      "cpu_baseline": cpu}), flush=True)
     eng.close()
 
 
-def adder_bench(args, torch, dev, eng):
-    """BASELINE configs[3]: W independent 32-bit ripple-carry adders, the reference's full_adder_MUX gate sequence
-    (src/test/test-addition-boot.cpp:30-67), levelized over a device-resident ciphertext pool and compiled once
-    (tfhe_hip_netlist_create: validation, job upload, one hipGraph over all levels); a step is one replay.
-    TFHE_BENCH_LEVEL_BY_LEVEL=1 runs one tfhe_hip_gate_level_dev call per level instead.
-    The reference evaluates the same circuit as 32 x 4 sequential gate calls."""
+def netlist_bench(args, torch, dev, eng, mode):
+    """BASELINE configs[3]: W independent 32-bit ripple-carry adders (full_adder_MUX) or comparators (comparison_MUX),
+    the reference's gate sequences (src/test/test-addition-boot.cpp:30-115), levelized over a device-resident
+    ciphertext pool and compiled once (tfhe_hip_netlist_create: validation, job upload, one hipGraph over all levels);
+    a step is one replay.  TFHE_BENCH_LEVEL_BY_LEVEL=1 runs one tfhe_hip_gate_level_dev call per level instead.
+    The reference evaluates the same circuit as sequential gate calls."""
     from tfhe_amd import Client, Gate, PARAMS as PR
-    from tfhe_amd.netlist import Netlist, full_adder_mux
+    from tfhe_amd.netlist import Netlist, comparison_mux, full_adder_mux
     W, nbits = args.instances, 32
+    cmp_ = args.workload == "comparator"
     nl = Netlist()
     x, y = nl.input("x", nbits), nl.input("y", nbits)
-    nl.output("out", full_adder_mux(nl, x, y))
+    nl.output("out", (comparison_mux if cmp_ else full_adder_mux)(nl, x, y))
     client = Client()
     keys = client.keygen(42)
     eng.load_keys_coef(keys.bk_coef, keys.ks)
@@ -144,12 +252,12 @@ def adder_bench(args, torch, dev, eng):
     xb = ((xs[:, None] >> shifts) & 1).astype(np.uint8).reshape(-1)
     yb = ((ys[:, None] >> shifts) & 1).astype(np.uint8).reshape(-1)
     rows = W * nl.n_wires
-    pool = torch.zeros((rows, PR.n + 1), dtype=torch.int32, device=dev)
     base = (np.arange(W) * nl.n_wires)[:, None]
-    pool[torch.from_numpy((base + np.array(x)[None, :]).reshape(-1)).to(dev)] = \
-        torch.from_numpy(client.encrypt(keys, xb, seed=71)).to(dev)
-    pool[torch.from_numpy((base + np.array(y)[None, :]).reshape(-1)).to(dev)] = \
-        torch.from_numpy(client.encrypt(keys, yb, seed=72)).to(dev)
+    cx, cy = client.encrypt(keys, xb, seed=71), client.encrypt(keys, yb, seed=72)
+    pool = torch.zeros((rows, PR.n + 1), dtype=torch.int32, device=dev)
+    pool[torch.from_numpy((base + np.array(x)[None, :]).reshape(-1)).to(dev)] = torch.from_numpy(cx).to(dev)
+    pool[torch.from_numpy((base + np.array(y)[None, :]).reshape(-1)).to(dev)] = torch.from_numpy(cy).to(dev)
+    torch.cuda.synchronize()    # stream contract: torch's writes land before the engine's stream reads the pool
     levels = nl.level_arrays(instances=W)
     ngates = sum(int((lv[:, 0] <= int(Gate.MUX)).sum()) for lv in levels)
     nboot = sum(int((lv[:, 0] < int(Gate.MUX)).sum()) + 2 * int((lv[:, 0] == int(Gate.MUX)).sum()) for lv in levels)
@@ -167,24 +275,80 @@ def adder_bench(args, torch, dev, eng):
     for _ in range(args.warmup):
         run()
     eng.sync()
+    # device time of one pass: events on the engine's own stream (torch.cuda.Event would see torch's stream only)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    es = torch.cuda.ExternalStream(eng.stream(), device=dev)
+    ev0.record(es)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
+    ev1.record(es)
     eng.sync()
     dt = (time.perf_counter() - t0) / args.steps
+    pass_ms = ev0.elapsed_time(ev1) / args.steps
     out_rows = torch.from_numpy((base + np.array(nl.outputs["out"])[None, :]).reshape(-1)).to(dev)
+    nout = len(nl.outputs["out"])
     bits, _ = client.decrypt(keys, pool[out_rows].cpu().numpy())
-    got = (bits.reshape(W, nbits + 1).astype(np.int64) << np.arange(nbits + 1)).sum(axis=1)
-    assert np.array_equal(got, xs + ys), "adder outputs decrypt wrongly"
-    print(json.dumps({"metric": "bootstrapped gates/sec, levelized 32-bit adders (full_adder_MUX netlist)",
+    got = (bits.reshape(W, nout).astype(np.int64) << np.arange(nout)).sum(axis=1)
+    assert np.array_equal(got, (xs <= ys).astype(np.int64) if cmp_ else xs + ys), "netlist outputs decrypt wrongly"
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the same circuit on the host cores: `threads` instances, the reference's gates (one kind at a time per level)
+        threads = _cpu_threads()
+        Wc = threads
+        clevels = nl.level_arrays(instances=Wc)
+        cpool = np.zeros((Wc * nl.n_wires, PR.n + 1), np.int32)
+        cbase = (np.arange(Wc) * nl.n_wires)[:, None]
+        cpool[(cbase + np.array(x)[None, :]).reshape(-1)] = cx[:Wc * nbits]
+        cpool[(cbase + np.array(y)[None, :]).reshape(-1)] = cy[:Wc * nbits]
+        cgates, kind = 0, "port"
+        t1 = time.perf_counter()
+        for lv in clevels:
+            outs = {}
+            for g in np.unique(lv[:, 0]):
+                sel = lv[lv[:, 0] == g]
+                if g > int(Gate.MUX):     # NOT / COPY / CONSTANT: linear, no bootstrap
+                    if g == int(Gate.COPY):
+                        outs[int(g)] = (sel[:, 1], cpool[sel[:, 2]].copy())
+                    elif g == int(Gate.NOT):
+                        outs[int(g)] = (sel[:, 1], (-cpool[sel[:, 2]].astype(np.int64)).astype(np.int32))
+                    else:
+                        v = np.zeros((sel.shape[0], PR.n + 1), np.int32)
+                        v[:, PR.n] = PR.MU if g == int(Gate.CONST1) else -PR.MU
+                        outs[int(g)] = (sel[:, 1], v)
+                    continue
+                a_, b_ = np.ascontiguousarray(cpool[sel[:, 2]]), np.ascontiguousarray(cpool[sel[:, 3]])
+                c_ = np.ascontiguousarray(cpool[sel[:, 4]]) if g == int(Gate.MUX) else None
+                o_, _, kind = cpu_gates(keys, int(g), a_, b_, c_, threads)
+                outs[int(g)] = (sel[:, 1], o_)
+                cgates += sel.shape[0]
+            for rows_, vals in outs.values():
+                cpool[rows_] = vals
+        cdt = time.perf_counter() - t1
+        cbits, _ = client.decrypt(keys, cpool[(cbase + np.array(nl.outputs["out"])[None, :]).reshape(-1)])
+        cgot = (cbits.reshape(Wc, nout).astype(np.int64) << np.arange(nout)).sum(axis=1)
+        assert np.array_equal(cgot, got[:Wc]), "CPU and GPU evaluations of the circuit disagree"
+        cpu = {"value": cgates / cdt, "unit": "gates/s", "cores": threads, "kind": kind,
+               "host_cores_available": len(os.sched_getaffinity(0)),
+               "sample": "%d instances of the same 32-bit circuit (%d bootstrapped gates) level by level on %d threads, "
+                         "%.1f s wall; decrypted results equal the GPU's" % (Wc, cgates, threads, cdt)}
+    name = "comparators (comparison_MUX netlist)" if cmp_ else "adders (full_adder_MUX netlist)"
+    print(json.dumps({"metric": "bootstrapped gates/sec, levelized 32-bit " + name,
                       "value": ngates / dt, "unit": "gates/s", "n_gpus": 1, "steps": args.steps,
-                      "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "f64",
-                      "data": "synthetic",
-                      "config": {"workload": "adder", "instances": W, "bits": nbits, "levels": len(levels),
+                      "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": "%s: %d instances x 32 bits, %s arithmetic (BASELINE configs[3])"
+                                             % (args.workload, W, mode.upper()),
+                                 "arithmetic": mode, "instances": W, "bits": nbits, "levels": len(levels),
                                  "evaluation": "level by level" if by_level else
                                  ("compiled netlist, hipGraph" if compiled.is_graph else "compiled netlist, direct enqueue"),
                                  "gates_per_step": ngates, "bootstraps_per_step": nboot,
-                                 "additions_per_s": W / dt, "sums_decrypt_correctly": True}}), flush=True)
+                                 "circuits_per_s": W / dt, "results_decrypt_correctly": True},
+                      "roofline": _roofline("k_blind_rotate (all levels of one pass)", FLOP_PER_BOOTSTRAP * nboot, pass_ms,
+                                            "FP64 vector ALUs; launch = one pass over all levels (blind rotations, "
+                                            "keyswitches and linear kernels of the hipGraph), HIP events on the engine's stream"),
+                      "cpu_baseline": cpu}), flush=True)
     if compiled is not None:
         compiled.close()
     eng.close()
@@ -199,9 +363,9 @@ def main():
                     help="gates per GPU per step; default 16384 on one GPU (BASELINE configs[1]) and 2^20 / 8 = 131072 on "
                          "several (on 8 GPUs the job is BASELINE configs[2]: 2^20 gates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="nand", choices=["nand", "mux", "fft", "fft2048", "adder"],
-                    help="nand: BASELINE configs[1] (default, the headline); adder: configs[3] levelized 32-bit adders; "
-                         "mux / fft: configs[4] side benches")
+    ap.add_argument("--workload", default="nand", choices=["nand", "mux", "fft", "fft2048", "adder", "comparator"],
+                    help="nand: BASELINE configs[1] (default, the headline); adder / comparator: configs[3] levelized "
+                         "32-bit circuits; mux / fft / fft2048: configs[4] side benches")
     ap.add_argument("--instances", type=int, default=4096, help="adder workload: independent adder instances")
     ap.add_argument("--arith", default="both", choices=["exact", "fast", "both"],
                     help="arithmetic of the FP64 stage (tfhe_hip_set_arithmetic): exact = bit-identical to the reference; "
@@ -219,7 +383,7 @@ def main():
         raise SystemExit("--param-set 80 is measured on the nand workload only")
 
     if args.batch is None:
-        args.batch = 16384 if args.gpus == 1 else (1 << 20) // 8
+        args.batch = 16384 if (args.gpus == 1 or args.workload != "nand") else (1 << 20) // 8
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -1798,6 +1798,7 @@ struct tfhe_hip_ctx {
     std::vector<uint8_t> h_mark;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // br start/stop, ks start/stop
     bool ev_br = false, ev_ks = false;
+    bool in_mul2048 = false;  // the N = 2048 product is running its four N = 1024 products
     long long fault_chunk = -1;  // test hook: fail the host pipeline at this chunk once (TFHE_HIP_TEST_FAIL_CHUNK)
     int br_waves = 0;  // 0 = by batch size; TFHE_HIP_BR_WAVES=1|4|8 forces a shape, 6 the one-workgroup-per-ciphertext kernel
 };
@@ -2675,6 +2676,11 @@ int tfhe_hip_negacyclic_mul_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const int
     if (int r = check_ctx(c, false)) return r;
     if (count < 0 || (count > 0 && (!d_out || !d_i || !d_t))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
     if (count == 0) return TFHE_HIP_OK;
+    const bool timed = !c->in_mul2048;  // tfhe_hip_last_kernel_ms: events around this call's kernel (the N = 2048 call brackets its own)
+    if (timed) {
+        c->ev_br = c->ev_ks = false;
+        HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    }
     if (c->arith == TFHE_HIP_ARITH_FAST) {
         HIPCHK(hipFuncSetAttribute((const void *) k_poly_mul_fast, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLdsFast));
         hipLaunchKernelGGL(k_poly_mul_fast, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLdsFast, c->stream, d_i, d_t,
@@ -2685,6 +2691,10 @@ int tfhe_hip_negacyclic_mul_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const int
                            (const c64 *) c->tw, c->ka, (long long) count);
     }
     HIPCHK(hipGetLastError());
+    if (timed) {
+        HIPCHK(hipEventRecord(c->ev[1], c->stream));
+        c->ev_br = true;
+    }
     return TFHE_HIP_OK;
 }
 int tfhe_hip_negacyclic_mul_batch(tfhe_hip_ctx *c, int32_t *out, const int32_t *ip, const int32_t *tp, int64_t count) {
@@ -2708,6 +2718,13 @@ int tfhe_hip_negacyclic_mul2048_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const
     constexpr int64_t kChunk = 8192;  // workspace: 3 x 4 x 4 KB per product
     const int64_t first = count < kChunk ? count : kChunk;
     if (count > 0) HIPCHK(c->misc.reserve((size_t) first * 12 * kN * sizeof(int32_t)));
+    c->ev_br = c->ev_ks = false;
+    if (count > 0) HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    struct Flag {
+        bool &f;
+        ~Flag() { f = false; }
+    } flag{c->in_mul2048};
+    c->in_mul2048 = true;
     for (int64_t off = 0; off < count; off += kChunk) {
         const int64_t n = count - off < kChunk ? count - off : kChunk;
         int32_t *I = (int32_t *) c->misc.p, *T = I + (size_t) first * 4 * kN, *P = T + (size_t) first * 4 * kN;
@@ -2719,6 +2736,10 @@ int tfhe_hip_negacyclic_mul2048_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const
         hipLaunchKernelGGL(k_combine2048, dim3(blocks), dim3(256), 0, c->stream, (const int32_t *) P, d_out + off * 2 * kN,
                            (long long) n);
         HIPCHK(hipGetLastError());
+    }
+    if (count > 0) {
+        HIPCHK(hipEventRecord(c->ev[1], c->stream));
+        c->ev_br = true;
     }
     return TFHE_HIP_OK;
 }
