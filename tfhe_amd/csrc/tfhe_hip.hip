@@ -43,9 +43,20 @@ constexpr int kKsT = 8, kKsBasebit = 2;
 // ---------------------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------------------
+// Knock-out builds (-DTFHE_HIP_KO=mask; diagnostic only, results are WRONG, never shipped: tools/ko_build.sh): what the
+// kernel costs without its transposes (1), twiddle reads (2), key loads (4), rotated accumulator reads (8)
+#ifndef TFHE_HIP_KO
+#define TFHE_HIP_KO 0
+#endif
 struct TwLds {  // this lane's column of the per-lane twiddle image in LDS (br_core.h: tw_slot_index)
     const c64 *t;  // image + lane
-    __device__ __forceinline__ c64 operator()(int slot) const { return t[slot * 64]; }
+    __device__ __forceinline__ c64 operator()(int slot) const {
+#if TFHE_HIP_KO & 2
+        return c64{__builtin_amdgcn_readfirstlane(slot) * 1e-3 + 0.7, 0.7};
+#else
+        return t[slot * 64];
+#endif
+    }
 };
 
 // twiddles fetched ahead of the level that uses them
@@ -212,8 +223,13 @@ __device__ __forceinline__ void mac_col(c64 (&acc)[8], const c64 (&v)[8], const 
     for (int r = 0; r < 8; r++) cmac(acc[r], v[r], kb[r]);
 }
 __device__ __forceinline__ void load_col(c64 (&kb)[8], const c64 *row) {
+#if TFHE_HIP_KO & 4
+#pragma unroll
+    for (int r = 0; r < 8; r++) kb[r] = c64{0.25 + r, 0.5 - (double) ((size_t) row & 1)};
+#else
 #pragma unroll
     for (int r = 0; r < 8; r++) kb[r] = row[r * 64];
+#endif
 }
 // halves (h = fixed y3) of the inverse transposes through the 8 KB scratch
 template <int H>
@@ -437,18 +453,30 @@ __device__ __forceinline__ void mac_col_f(c64 (&acc)[8], const c64 (&v)[8], cons
     for (int r = 0; r < 8; r++) brf::cmac(acc[r], v[r], kb[r]);
 }
 __device__ __forceinline__ void t_write_A(c64 *scratch, const c64 (&v)[8], int lane) {
+#if TFHE_HIP_KO & 1
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 8; r++) scratch[swz(fwd_xA(lane, r))] = v[r];
 }
 __device__ __forceinline__ void t_write_B(c64 *scratch, const c64 (&v)[8], int lane) {
+#if TFHE_HIP_KO & 1
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 8; r++) scratch[swz(fwd_xB(lane, r))] = v[r];
 }
 __device__ __forceinline__ void t_read_B(c64 (&v)[8], const c64 *scratch, int lane) {
+#if TFHE_HIP_KO & 1
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xB(lane, r))];
 }
 __device__ __forceinline__ void t_read_C(c64 (&v)[8], const c64 *scratch, int lane) {
+#if TFHE_HIP_KO & 1
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xC(lane, r))];
 }
@@ -497,6 +525,11 @@ __device__ __forceinline__ void fwd_step_fast(const int t, c64 (&v)[8], const c6
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int j = (br3(r) << 6) | lane;
+#if TFHE_HIP_KO & 8
+            tlo[r] = decomp_prepare(j * bara + c);
+            thi[r] = decomp_prepare(j - bara);
+            continue;
+#endif
             if (ROTATE) {
                 tlo[r] = decomp_prepare(rot_minus_one(accc, bara, j));
                 thi[r] = decomp_prepare(rot_minus_one(accc, bara, j + kNh));
@@ -623,6 +656,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
     if (g >= A.B) return;  // wave-uniform; no workgroup barrier after this point
     const PhaseAConsts twu = A.ka;
     const TwLds twl{tw_lds + lane};
+    constexpr bool kKeySync = WAVES > 1;  // one workgroup barrier per CMux iteration (both arithmetic modes)
 
     if (MODE == MODE_GATE) {
         // tfhe_bootstrap_woKS_FFT (lwe-bootstrapping-functions-fft.cpp:222-253) with the gate's linear
@@ -659,7 +693,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
 #pragma unroll 1
         for (int i = 0; i < kLwe; i++) {
             const int bara = __builtin_amdgcn_readfirstlane(modswitch_2N(comb(i)));
-            if (bara == 0) continue;  // lwe-bootstrapping-functions-fft.cpp:154
+            if (kKeySync) {
+                // All waves of the workgroup enter iteration i together: the 96 KB of bk_i that every wave streams then
+                // come out of the CU's vector cache for all but the first of them instead of once per wave out of L2
+                // (1 TB per 16,384-gate launch, 48 of the ~70 GB/s a CU gets from its L2).  A rotation by 0 is not
+                // skipped here, so that every wave meets every barrier: (X^0 - 1) ACC = 0 decomposes into zero digits
+                // and adds exactly nothing in either arithmetic mode (the exact-mode parity tests cover such iterations), as in the
+                // reference's device loop (src/kernels/tfhe_blindRotate_FFT.cpp:18-28).  Measured: 122.0 -> 118.4 ms (exact), 80.7 -> 76.9 ms (fast).
+                // Waves that have ended (ragged last workgroup) are left out of the barrier by the hardware.
+                __builtin_amdgcn_s_barrier();
+            } else if (bara == 0) {
+                continue;  // lwe-bootstrapping-functions-fft.cpp:154
+            }
             if (FAST) cmux_fast<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
             else cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
         }
@@ -688,7 +733,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
 #pragma unroll 1
             for (int i = 0; i < kLwe; i++) {
                 const int bara = __builtin_amdgcn_readfirstlane(gbara[i]) & (2 * kN - 1);
-                if (bara == 0) continue;
+                if (kKeySync) __builtin_amdgcn_s_barrier();
+                else if (bara == 0) continue;
                 if (FAST) cmux_fast<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
                 else cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
             }
