@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(192) void k_keyswitch(const int32_t *__restrict__ i
 // 16-byte loads from the key stored as int8[i][limb][q][j][d].
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kKsQ = (kCt + 127) / 128 * 128;  // output coefficients padded to whole workgroups of 4 x 32 (640)
-constexpr int kKsYB = kKsQ / 128;            // workgroups over the coefficients (5)
+constexpr int kKsYB = kKsQ / 32;             // workgroups over the coefficients (20), each 4 waves x 32*MT ciphertexts
 constexpr int kKsMT = 2;      // 32-ciphertext tiles per wave
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
@@ -1122,7 +1122,12 @@ __global__ void k_ks_pack_mfma(int8_t *__restrict__ dst, const int32_t *__restri
     }
 }
 
-// in[B][N+1] -> abarT[N][Bp] = a_i + 2^15 (lwe-keyswitch-functions.cpp:119,123); padding ciphertexts get digit 0
+// in[B][N+1] -> abarT = a_i + 2^15 (lwe-keyswitch-functions.cpp:119,123) in the order the keyswitch waves read it:
+// [ciphertext tile of 64][i / 4][M-tile of 32][ciphertext in tile][i % 4], so that a lane's four consecutive steps are
+// one 16-byte load; padding ciphertexts get digit 0
+__device__ __forceinline__ size_t ks_abar_index4(long long g, int i) {  // index of the 16-byte group holding (g, i)
+    return ((((size_t) (g >> 6) * (kN / 4) + (i >> 2)) * 2 + ((g >> 5) & 1)) << 5) + (g & 31);
+}
 __global__ void k_ks_transpose(uint32_t *__restrict__ abarT, const int32_t *__restrict__ in, long long B, long long Bp,
                                const KsJob *__restrict__ kj) {
     __shared__ uint32_t tile[32][33];
@@ -1146,23 +1151,38 @@ __global__ void k_ks_transpose(uint32_t *__restrict__ abarT, const int32_t *__re
         tile[r][tx] = v;
     }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) abarT[(size_t) (i0 + r) * Bp + g0 + tx] = tile[tx][r];
+    (void) Bp;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int gl = threadIdx.x & 31, i4 = threadIdx.x >> 5;  // 32 ciphertexts x 8 groups of four steps
+    reinterpret_cast<u32x4 *>(abarT)[ks_abar_index4(g0 + gl, i0 + 4 * i4)] =
+        u32x4{tile[gl][4 * i4], tile[gl][4 * i4 + 1], tile[gl][4 * i4 + 2], tile[gl][4 * i4 + 3]};
 }
 
-// grid (Bp/(32*MT), 5, S), block 256: wave w of block (x, y) owns 32*MT ciphertexts and coefficients
-// [32(4y+w), 32(4y+w)+32); all four limbs accumulate in one pass over i (A fragments built once per i).
-// Small batches cannot fill the chip with x * 5 blocks (a single gate: 5 blocks streaming 84 MB of key, 0.7 ms), so the
+// grid (ceil(Bp/(4*32*MT)), 20, S), block 256: block (x, y) owns the 32 coefficients [32y, 32y+32) and 4 x 32*MT
+// ciphertexts, wave w of it the ciphertexts [(4x+w) 32 MT, +32 MT).  The four waves of a block therefore read the SAME key
+// tile in every step (they run the same loop side by side, so three of the four reads are served by the CU's vector
+// cache), and each key byte leaves L2 once per 256 ciphertexts instead of once per 64: the kernel was bound by exactly
+// that stream (21.5 GB through L2 per 16,384-ciphertext launch).  All four limbs accumulate in one pass over i (A
+// fragments built once per i).
+// Small batches cannot fill the chip with x * 20 blocks (a single gate: 20 blocks streaming 84 MB of key), so the
 // input coefficients i are split S ways (blockIdx.z) into `partial`, and k_ks_reduce adds the parts (integer sums:
 // any order gives the same bits).
 __global__ __launch_bounds__(256, 2) void k_keyswitch_mfma(const uint32_t *__restrict__ abarT, const int8_t *__restrict__ kl,
                                                         const int32_t *__restrict__ in, int32_t *__restrict__ out,
                                                         long long B, long long Bp, const KsJob *__restrict__ kj,
                                                         uint32_t *__restrict__ partial) {
+    // The key tile of a step (4 limbs x 1 KB) is fetched once per block - wave w brings limb w - and handed to the other
+    // waves through LDS (three tiles in rotation, one workgroup barrier per step); every wave reads the tile of step i+1
+    // into registers while its matrix instructions of step i run.  Before, every wave fetched every tile for itself:
+    // 72 B per clock and CU at the MFMA rate, more than the vector memory path of a CU delivers.
+    __shared__ v4i_t tile[3][4][64];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r32 = lane & 31, h = lane >> 5;
-    const long long g0 = (long long) blockIdx.x * (32 * kKsMT);
-    const int q = (blockIdx.y * 4 + wave) * 32 + r32;
-    const uint32_t *ap = abarT + g0 + r32;
+    const long long g0 = ((long long) blockIdx.x * 4 + wave) * (32 * kKsMT);
+    const bool live = g0 < Bp;  // ragged last block: a wave without ciphertexts still fetches its limb and meets the barriers
+    const int q = blockIdx.y * 32 + r32;
+    const u32x4 *ap = reinterpret_cast<const u32x4 *>(abarT) + ks_abar_index4(live ? g0 + r32 : r32, 0);  // + 64 per i/4, + 32 per M-tile
     const v4i_t *bp = reinterpret_cast<const v4i_t *>(kl) + (size_t) q * 2 + h;
     v16i_t acc[4][kKsMT];
 #pragma unroll
@@ -1171,26 +1191,56 @@ __global__ __launch_bounds__(256, 2) void k_keyswitch_mfma(const uint32_t *__res
         for (int m = 0; m < kKsMT; m++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[l][m][r] = 0;
-    const int i_per = kN / (int) gridDim.z, i_lo = (int) blockIdx.z * i_per;
-#pragma unroll 2
-    for (int i = i_lo; i < i_lo + i_per; i++) {
-        v4i_t b[4];
+    const int i_per = kN / (int) gridDim.z, i_lo = (int) blockIdx.z * i_per, i_hi = i_lo + i_per;  // multiples of 4
+    auto key = [&](int i) { return bp[((size_t) i * 4 + wave) * kKsQ * 2]; };
+    tile[0][wave][lane] = key(i_lo);
+    tile[1][wave][lane] = key(i_lo + 1);
+    v4i_t gnext = key(i_lo + 2);  // in flight: the limb of step i + 2
+    __syncthreads();
+    v4i_t bcur[4], bnxt[4];
 #pragma unroll
-        for (int l = 0; l < 4; l++) b[l] = bp[((size_t) i * 4 + l) * kKsQ * 2];
+    for (int l = 0; l < 4; l++) bcur[l] = tile[0][l][lane];
+    u32x4 a4[kKsMT], a4n[kKsMT];
+#pragma unroll
+    for (int m = 0; m < kKsMT; m++) a4n[m] = ap[(size_t) (i_lo >> 2) * 64 + 32 * m];
+#pragma unroll 1
+    for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
 #pragma unroll
         for (int m = 0; m < kKsMT; m++) {
-            const uint32_t ab = ap[(size_t) i * Bp + 32 * m];
-            v4i_t a;
+            a4[m] = a4n[m];
+            if (i0 + 4 < i_hi) a4n[m] = ap[(size_t) ((i0 + 4) >> 2) * 64 + 32 * m];
+        }
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                // digit j = 4h + jj: ((ab >> (30 - 2j)) & 3); one-hot byte position = digit
-                const uint32_t sh = (ab >> (27 - 2 * jj - 8 * h)) & 24u;
-                a[jj] = (int) (1u << sh);
+        for (int ii = 0; ii < 4; ii++) {
+            const int i = i0 + ii, s1 = (i - i_lo + 1) % 3, s2 = (i - i_lo + 2) % 3;
+            // tile of step i + 1 (complete since the last barrier) -> registers; the limb of step i + 2 -> LDS; request i + 3
+            if (i + 1 < i_hi) {
+#pragma unroll
+                for (int l = 0; l < 4; l++) bnxt[l] = tile[s1][l][lane];
             }
+            if (i + 2 < i_hi) tile[s2][wave][lane] = gnext;
+            if (i + 3 < i_hi) gnext = key(i + 3);
+            if (live) {
 #pragma unroll
-            for (int l = 0; l < 4; l++) acc[l][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[l], acc[l][m], 0, 0, 0);
+                for (int m = 0; m < kKsMT; m++) {
+                    const uint32_t ab = a4[m][ii];
+                    v4i_t a;
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        // digit j = 4h + jj: ((ab >> (30 - 2j)) & 3); one-hot byte position = digit
+                        const uint32_t sh = (ab >> (27 - 2 * jj - 8 * h)) & 24u;
+                        a[jj] = (int) (1u << sh);
+                    }
+#pragma unroll
+                    for (int l = 0; l < 4; l++) acc[l][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bcur[l], acc[l][m], 0, 0, 0);
+                }
+            }
+            __syncthreads();  // tile s2 is complete; nobody reads the tile of step i any more (it is written next at i + 1)
+#pragma unroll
+            for (int l = 0; l < 4; l++) bcur[l] = bnxt[l];
         }
     }
+    if (!live) return;
     if (q > kLwe) return;
 #pragma unroll
     for (int m = 0; m < kKsMT; m++)
@@ -1941,8 +1991,9 @@ struct KsWork {
     size_t part_bytes;
 };
 // split of the input coefficients over block groups for a batch of Bp (padded) ciphertexts: fill the 256 CUs
+long long ks_xblocks(long long Bp) { return (Bp / (32 * kKsMT) + 3) / 4; }
 int ks_split(long long Bp) {
-    const long long xblocks = Bp / (32 * kKsMT);
+    const long long xblocks = ks_xblocks(Bp);
     int S = 1;
     while (S < 16 && kKsYB * xblocks * S < 256) S *= 2;
     return S;
@@ -1962,7 +2013,7 @@ int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B,
             abart = (uint32_t *) c->abart.p;
         }
         hipLaunchKernelGGL(k_ks_transpose, dim3((unsigned) (Bp / 32), kN / 32), dim3(256), 0, c->stream, abart, d_in, B, Bp, kj);
-        const long long xblocks = Bp / (32 * kKsMT);
+        const long long xblocks = ks_xblocks(Bp);
         int S = ks_split(Bp);
         if (ws)  // a fixed workspace: as many parts as fit (any split gives the same bits: integer sums)
             while (S > 1 && (size_t) S * Bp * kCt * sizeof(uint32_t) > ws->part_bytes) S /= 2;
