@@ -188,6 +188,23 @@ int tfhe_hip_negacyclic_mul_batch(tfhe_hip_ctx *ctx, int32_t *out, const int32_t
 int tfhe_hip_negacyclic_mul_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_ipolys,
                                       const int32_t *d_tpolys, int64_t count);
 
+/* ---- leveled TGSW / TLWE operations on caller-supplied operands ---------------------------------
+ * acc[count][2][N] in/out; operand g of the call is entry index[g] of the operand array (ntgsw entries), so that many
+ * accumulators can share a few TGSW samples.  Results in the context's arithmetic mode (EXACT: the reference's bit for bit).
+ * tGswFFTExternMulToTLwe (tgsw-fft-operations.cpp:92-120): gsw_fft double[ngsw][2l][2][N/2][2] = TGswSampleFFT
+ *   .all_samples[p].a[c].coefsC (what tGswToFFTConvert, :52-57, = tfhe_hip_torus_ifft_batch per polynomial, produces). */
+int tfhe_hip_tgsw_fft_extern_mul_batch(tfhe_hip_ctx *ctx, int32_t *acc, const double *gsw_fft, const int32_t *gsw_index,
+                                       int64_t ngsw, int64_t count);
+/* tGswExternMulToTLwe (tgsw-functions.cpp:157-170; tGswExternProduct, :338-352, is the same computation into another
+ * sample): tgsw int32[ntgsw][2l][2][N] = TGswSample.all_sample[p].a[c].coefsT, coefficient domain; every (row, column)
+ * product goes through torusPolynomialAddMulRFFT (polynomials.cpp:249-259) as in the reference. */
+int tfhe_hip_tgsw_extern_mul_batch(tfhe_hip_ctx *ctx, int32_t *acc, const int32_t *tgsw, const int32_t *tgsw_index,
+                                   int64_t ntgsw, int64_t count);
+/* tLweAddMulRTo (tlwe-functions.cpp:191-197): result[g] += poly[g] * sample[g]; result, sample int32[count][2][N],
+ * poly int32[count][N] (an IntPolynomial) */
+int tfhe_hip_tlwe_addmul_r_batch(tfhe_hip_ctx *ctx, int32_t *result, const int32_t *poly, const int32_t *sample,
+                                 int64_t count);
+
 /* the same product at N = 2048 (BASELINE configs[4]): polys int32[count][2048].  The reference has no transform for
  * N = 2048 (tfhe_core.h:14); the product is composed of four N = 1024 products (even/odd split) and agrees with the
  * reference's naive product torusPolynomialMultNaive_aux (multiplication.cpp:31-43) within 2 LSB for |ipoly| < 2N */

@@ -497,3 +497,51 @@ void ref80_extern_mul(int32_t *acc /*[2][N] in/out*/, double *bkfft_out /*may be
     delete_TLweSample(accum); delete_TGswSampleFFT(gsw); delete_TGswSample(s);
 }
 }  // extern "C"
+
+// ---- leveled operations on arbitrary operands (default parameter set): tGswExternMulToTLwe (tgsw-functions.cpp:157-170),
+// tGswFFTExternMulToTLwe with a caller-built TGswSampleFFT (tgsw-fft-operations.cpp:52-57,92-120), tLweAddMulRTo
+// (tlwe-functions.cpp:191-197)
+extern "C" {
+static TGswSample *tgsw_from_flat(const int32_t *tgsw) {
+    ensure_params();
+    TGswSample *s = new_TGswSample(g_params->tgsw_params);
+    for (int p = 0; p < kpl_; p++) {
+        for (int c = 0; c < 2; c++) memcpy(s->all_sample[p].a[c].coefsT, tgsw + ((size_t) p * 2 + c) * N_, sizeof(int32_t) * N_);
+        s->all_sample[p].current_variance = 0.;
+    }
+    return s;
+}
+void ref_tgsw_extern_mul(int32_t *acc /*[2][N] in/out*/, const int32_t *tgsw /*[kpl][2][N]*/) {
+    TGswSample *s = tgsw_from_flat(tgsw);
+    TLweSample *a = new_TLweSample(g_params->tgsw_params->tlwe_params);
+    to_tlwe(a, acc);
+    tGswExternMulToTLwe(a, s, g_params->tgsw_params);
+    from_tlwe(acc, a);
+    delete_TLweSample(a); delete_TGswSample(s);
+}
+void ref_tgsw_fft_extern_mul(int32_t *acc /*[2][N] in/out*/, double *gsw_fft_out /*[kpl][2][N/2][2]*/, const int32_t *tgsw) {
+    TGswSample *s = tgsw_from_flat(tgsw);
+    TGswSampleFFT *f = new_TGswSampleFFT(g_params->tgsw_params);
+    tGswToFFTConvert(f, s, g_params->tgsw_params);
+    for (int p = 0; p < kpl_; p++)
+        for (int c = 0; c < 2; c++)
+            memcpy(gsw_fft_out + ((size_t) p * 2 + c) * N_, f->all_samples[p].a[c].coefsC, sizeof(double) * N_);
+    TLweSample *a = new_TLweSample(g_params->tgsw_params->tlwe_params);
+    to_tlwe(a, acc);
+    tGswFFTExternMulToTLwe(a, f, g_params->tgsw_params);
+    from_tlwe(acc, a);
+    delete_TLweSample(a); delete_TGswSampleFFT(f); delete_TGswSample(s);
+}
+void ref_tlwe_addmul_r(int32_t *result /*[2][N] in/out*/, const int32_t *poly /*N*/, const int32_t *sample /*[2][N]*/) {
+    ensure_params();
+    const TLweParams *tp = g_params->tgsw_params->tlwe_params;
+    TLweSample *r = new_TLweSample(tp), *s = new_TLweSample(tp);
+    IntPolynomial *p = new_IntPolynomial();
+    to_tlwe(r, result);
+    to_tlwe(s, sample);
+    memcpy(p->coefs, poly, sizeof(int32_t) * N_);
+    tLweAddMulRTo(r, p, s, tp);
+    from_tlwe(result, r);
+    delete_IntPolynomial(p); delete_TLweSample(s); delete_TLweSample(r);
+}
+}  // extern "C"

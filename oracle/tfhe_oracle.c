@@ -354,16 +354,15 @@ void oracle_keys_free(oracle_keys *k) {
  * --------------------------------------------------------------------------------------------------------- */
 /* tgsw-fft-operations.cpp:92-120: decompose both polynomials, 6 forward transforms, accumulate rows p = 0..5
  * into a cleared spectrum pair (tlwe-fft-operations.cpp:80-94), 2 inverse transforms */
-void oracle_externMul(const oracle_keys *k, int32_t *acc, int32_t i) {
+void oracle_externMulFFT(int32_t *acc, const double *gsw /*[kpl][2][N/2][2]*/) {
     int32_t deca[ORC_kpl * N];
     double decaFFT[ORC_kpl][N], tmpa[2][N];
     for (int c = 0; c < 2; c++) oracle_decompH(deca + c * ORC_l * N, acc + c * N);
     for (int p = 0; p < ORC_kpl; p++) oracle_IntPolynomial_ifft(decaFFT[p], deca + p * N);
     memset(tmpa, 0, sizeof(tmpa));
-    const double *bki = k->bkfft + (size_t) i * ORC_kpl * 2 * N;
     for (int p = 0; p < ORC_kpl; p++)
         for (int c = 0; c < 2; c++) {
-            const double *b = bki + (p * 2 + c) * N;
+            const double *b = gsw + (p * 2 + c) * N;
             for (int f = 0; f < NH; f++) {
                 double xr, xi;
                 cmul(&xr, &xi, decaFFT[p][2 * f], decaFFT[p][2 * f + 1], b[2 * f], b[2 * f + 1]);
@@ -372,6 +371,27 @@ void oracle_externMul(const oracle_keys *k, int32_t *acc, int32_t i) {
             }
         }
     for (int c = 0; c < 2; c++) oracle_TorusPolynomial_fft(acc + c * N, tmpa[c]);
+}
+void oracle_externMul(const oracle_keys *k, int32_t *acc, int32_t i) {
+    oracle_externMulFFT(acc, k->bkfft + (size_t) i * ORC_kpl * 2 * N);
+}
+
+/* tlwe-functions.cpp:191-197: result += p * sample, each column through torusPolynomialAddMulRFFT
+ * (polynomials.cpp:249-259: product transformed back and truncated on its own, then added mod 2^32) */
+void oracle_tLweAddMulRTo(int32_t *result /*[2][N]*/, const int32_t *p /*N*/, const int32_t *sample /*[2][N]*/) {
+    int32_t tmpr[N];
+    for (int c = 0; c < 2; c++) {
+        oracle_mulFFT(tmpr, p, sample + c * N);
+        for (int j = 0; j < N; j++) result[c * N + j] = add32(result[c * N + j], tmpr[j]);
+    }
+}
+/* tgsw-functions.cpp:157-170 (tGswExternMulToTLwe; tGswExternProduct, :338-352, computes the same into another sample):
+ * dec = tGswTLweDecompH(accum) (:264-270); accum = 0; accum += dec[i] * sample.all_sample[i] for the kpl rows in order */
+void oracle_tgswExternMulToTLwe(int32_t *acc /*[2][N] in/out*/, const int32_t *tgsw /*[kpl][2][N]*/) {
+    int32_t dec[ORC_kpl * N];
+    for (int c = 0; c < 2; c++) oracle_decompH(dec + c * ORC_l * N, acc + c * N);
+    memset(acc, 0, 2 * N * sizeof(int32_t));
+    for (int i = 0; i < ORC_kpl; i++) oracle_tLweAddMulRTo(acc, dec + i * N, tgsw + (size_t) i * 2 * N);
 }
 
 /* lwe-bootstrapping-functions-fft.cpp:68-77 */

@@ -61,6 +61,9 @@ void oracle_tgsw_to_fft(double *out /*[kpl][2][N/2][2]*/, const int32_t *in /*[k
 
 /* bootstrapping stages */
 void oracle_externMul(const oracle_keys *k, int32_t *acc /*[2][N] in/out*/, int32_t i);
+void oracle_externMulFFT(int32_t *acc /*[2][N] in/out*/, const double *gsw_fft /*[kpl][2][N/2][2]*/);
+void oracle_tLweAddMulRTo(int32_t *result /*[2][N]*/, const int32_t *p /*N*/, const int32_t *sample /*[2][N]*/);
+void oracle_tgswExternMulToTLwe(int32_t *acc /*[2][N] in/out*/, const int32_t *tgsw /*[kpl][2][N]*/);
 void oracle_muxRotate(const oracle_keys *k, int32_t *out /*[2][N]*/, const int32_t *acc, int32_t i, int32_t barai);
 void oracle_blindRotate(const oracle_keys *k, int32_t *acc /*[2][N] in/out*/, const int32_t *bara);
 void oracle_extract(int32_t *out /*N+1*/, const int32_t *acc);

@@ -105,6 +105,26 @@ class Oracle:
         self.lib.oracle_externMul(k, P(acc), ctypes.c_int32(i))
         return acc
 
+    def extern_mul_fft(self, acc, gsw_fft):
+        acc = i32(acc).copy()
+        self.lib.oracle_externMulFFT(P(acc), P(np.ascontiguousarray(gsw_fft, np.float64)))
+        return acc
+
+    def tgsw_extern_mul(self, acc, tgsw):
+        acc = i32(acc).copy()
+        self.lib.oracle_tgswExternMulToTLwe(P(acc), P(i32(tgsw)))
+        return acc
+
+    def tlwe_addmul_r(self, result, poly, sample):
+        res = i32(result).copy()
+        self.lib.oracle_tLweAddMulRTo(P(res), P(i32(poly)), P(i32(sample)))
+        return res
+
+    def tgsw_to_fft(self, tgsw):
+        out = np.empty((self.kpl, 2, N // 2, 2), np.float64)
+        self.lib.oracle_tgsw_to_fft(P(out), P(i32(tgsw)))
+        return out
+
     def mux_rotate(self, k, acc, i, barai):
         out = np.empty((2, N), np.int32)
         self.lib.oracle_muxRotate(k, P(out), P(i32(acc)), ctypes.c_int32(i), ctypes.c_int32(barai))

@@ -1593,6 +1593,52 @@ __global__ __launch_bounds__(256) void k_combine2048(const int32_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// leveled operations on caller-supplied operands: tGswExternMulToTLwe (tgsw-functions.cpp:157-170) and
+// tLweAddMulRTo (tlwe-functions.cpp:191-197).  The reference computes them row by row through torusPolynomialAddMulRFFT
+// (polynomials.cpp:249-259): every (row, column) product is transformed back and truncated on its own, the Torus32
+// results are added mod 2^32.  Here: operand lists for k_poly_mul (= torusPolynomialMultFFT) are laid out, all
+// products run as one batch, and the rows are summed in integers - the same values in any order.
+// ---------------------------------------------------------------------------------------------------------------
+// products (g, p, c): I = digit (p % l) of column (p / l) of acc[g] (tGswTLweDecompH, tgsw-functions.cpp:264-270),
+// T = tgsw[index[g]][p][c]
+__global__ __launch_bounds__(256) void k_tgsw_prepare(const int32_t *__restrict__ acc, const int32_t *__restrict__ tgsw,
+                                                      const int32_t *__restrict__ index, int32_t *__restrict__ I,
+                                                      int32_t *__restrict__ T, long long count) {
+    const long long idx = (long long) blockIdx.x * 256 + threadIdx.x;  // one thread per (g, p, j)
+    if (idx >= count * kKpl * kN) return;
+    const int j = (int) (idx & (kN - 1));
+    const long long gp = idx >> 10;
+    const int p = (int) (gp % kKpl);
+    const long long g = gp / kKpl;
+    const int32_t d = decomp_digit(decomp_prepare(acc[(g * 2 + p / kL) * kN + j]), p % kL);
+    const int32_t *row = tgsw + ((size_t) index[g] * kKpl + p) * 2 * kN;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        I[((g * kKpl + p) * 2 + c) * kN + j] = d;
+        T[((g * kKpl + p) * 2 + c) * kN + j] = row[c * kN + j];
+    }
+}
+// products (g, c): I = p[g], T = sample[g][c]
+__global__ __launch_bounds__(256) void k_addmul_prepare(const int32_t *__restrict__ poly, int32_t *__restrict__ I, long long count) {
+    const long long idx = (long long) blockIdx.x * 256 + threadIdx.x;  // one thread per (g, j)
+    if (idx >= count * kN) return;
+    const long long g = idx >> 10;
+    const int j = (int) (idx & (kN - 1));
+    I[(g * 2) * kN + j] = I[(g * 2 + 1) * kN + j] = poly[idx];
+}
+// out[g][c][j] = (ADD ? out : 0) + sum_{p < rows} P[g][p][c][j]
+template <bool ADD>
+__global__ __launch_bounds__(256) void k_rows_sum(int32_t *__restrict__ out, const int32_t *__restrict__ P, int rows, long long count) {
+    const long long idx = (long long) blockIdx.x * 256 + threadIdx.x;  // one thread per (g, c, j)
+    if (idx >= count * 2 * kN) return;
+    const int j = (int) (idx & (kN - 1)), c = (int) ((idx >> 10) & 1);
+    const long long g = idx >> 11;
+    uint32_t v = ADD ? (uint32_t) out[idx] : 0u;
+    for (int p = 0; p < rows; p++) v += (uint32_t) P[((g * rows + p) * 2 + c) * kN + j];
+    out[idx] = (int32_t) v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // client-side bulk operations on the GPU (the part that parallelises): bootsSymEncrypt
 // (tfhe_gate_bootstrapping.cpp:154-159 = lweSymEncrypt, lwe-functions.cpp:44-56) and lwePhase (:63-72).
 // The reference draws from std::default_random_engine + normal_distribution, whose streams are not portable; these
@@ -1907,7 +1953,7 @@ constexpr size_t kKsHostElems = (size_t) kN * kKsT * 4 * kCt;
 constexpr int kFftLds = kTwLaneEntries * (int) sizeof(c64) + 4 * kNh * (int) sizeof(c64);
 
 template <int MODE>
-int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
+int launch_br(tfhe_hip_ctx *c, const BrArgs &A0, const c64 *custom_bk = nullptr) {
     if (A0.B <= 0) return TFHE_HIP_OK;
     BrArgs A = A0;
 #ifdef TFHE_HIP_CLOCK_DIAG
@@ -1962,6 +2008,7 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0) {
         A.tw = c->twf;
         A.bk = c->bkf;
     }
+    if (custom_bk) A.bk = custom_bk;  // caller-supplied TGSW operands, already in the layout of the mode
     const size_t lds = (fast ? brf::kFastLaneEntries : kTwLaneEntries) * sizeof(c64) + (size_t) waves * kBrLdsPerWave;
     const unsigned grid = (unsigned) ((A.B + waves - 1) / waves);
     auto go = [&](auto kernel) -> int {
@@ -2852,6 +2899,98 @@ int tfhe_hip_negacyclic_mul2048_batch(tfhe_hip_ctx *c, int32_t *out, const int32
                                                       (const int32_t *) c->in_b.p, count))
         return r;
     return d2h(c, out, c->outb.p, pb);
+}
+
+// ---- leveled operations on caller-supplied operands -------------------------------------------------
+static int check_index(const int32_t *index, int64_t count, int64_t n) {
+    for (int64_t i = 0; i < count; i++)
+        if (index[i] < 0 || index[i] >= n) return fail(TFHE_HIP_ERR_ARG, "operand index out of range");
+    return TFHE_HIP_OK;
+}
+// tGswFFTExternMulToTLwe (tgsw-fft-operations.cpp:92-120) with TGswSampleFFT operands of the caller's
+int tfhe_hip_tgsw_fft_extern_mul_batch(tfhe_hip_ctx *c, int32_t *acc, const double *gsw_fft, const int32_t *gsw_index,
+                                       int64_t ngsw, int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || ngsw < 0 || (count > 0 && (!acc || !gsw_fft || !gsw_index || ngsw == 0)))
+        return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    if (int r = check_index(gsw_index, count, ngsw)) return r;
+    const size_t op_bytes = (size_t) ngsw * kKpl * 2 * kNh * sizeof(c64), ab = (size_t) count * 2 * kN * sizeof(int32_t);
+    const long long total = (long long) ngsw * kKpl * 2 * kNh;
+    const bool fast = c->arith == TFHE_HIP_ARITH_FAST;
+    // operand spectra: reference order -> physical slot order (in_c) -> (FAST) Z_k order (outb)
+    if (int r = h2d(c, c->misc, gsw_fft, op_bytes)) return r;
+    HIPCHK(c->in_c.reserve(op_bytes));
+    hipLaunchKernelGGL(k_bk_permute, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream, (c64 *) c->in_c.p,
+                       (const c64 *) c->misc.p, total, 1);
+    const c64 *op = (const c64 *) c->in_c.p;
+    if (fast) {
+        HIPCHK(c->outb.reserve(op_bytes));
+        hipLaunchKernelGGL(k_bk_to_fast, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream, (c64 *) c->outb.p,
+                           (const c64 *) c->in_c.p, total);
+        op = (const c64 *) c->outb.p;
+    }
+    HIPCHK(hipGetLastError());
+    if (int r = h2d(c, c->in_a, acc, ab)) return r;
+    if (int r = h2d(c, c->in_b, gsw_index, (size_t) count * sizeof(int32_t))) return r;
+    BrArgs A{};
+    A.acc_io = (int32_t *) c->in_a.p; A.bara = (const int32_t *) c->in_b.p; A.tw = c->tw; A.ka = c->ka; A.B = count;
+    c->ev_br = c->ev_ks = false;
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    if (int r = launch_br<MODE_EXTMUL>(c, A, op)) return r;
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    c->ev_br = true;
+    return d2h(c, acc, c->in_a.p, ab);
+}
+// products of the operand lists I, T (count2 = number of products) into P, in the arithmetic of the context
+static int mul_lists(tfhe_hip_ctx *c, int32_t *P, const int32_t *I, const int32_t *T, int64_t count2) {
+    return tfhe_hip_negacyclic_mul_batch_dev(c, P, I, T, count2);
+}
+// tGswExternMulToTLwe (tgsw-functions.cpp:157-170): acc[g] <- tgsw[index[g]] (*) acc[g], coefficient-domain operands
+int tfhe_hip_tgsw_extern_mul_batch(tfhe_hip_ctx *c, int32_t *acc, const int32_t *tgsw, const int32_t *tgsw_index,
+                                   int64_t ntgsw, int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || ntgsw < 0 || (count > 0 && (!acc || !tgsw || !tgsw_index || ntgsw == 0)))
+        return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    if (int r = check_index(tgsw_index, count, ntgsw)) return r;
+    const size_t ab = (size_t) count * 2 * kN * sizeof(int32_t), list = (size_t) count * kKpl * 2 * kN * sizeof(int32_t);
+    if (int r = h2d(c, c->in_a, acc, ab)) return r;
+    if (int r = h2d(c, c->in_b, tgsw, (size_t) ntgsw * kKpl * 2 * kN * sizeof(int32_t))) return r;
+    if (int r = h2d(c, c->in_c, tgsw_index, (size_t) count * sizeof(int32_t))) return r;
+    HIPCHK(c->misc.reserve(3 * list));
+    int32_t *I = (int32_t *) c->misc.p, *T = I + list / 4, *P = T + list / 4;
+    const long long n1 = (long long) count * kKpl * kN;
+    hipLaunchKernelGGL(k_tgsw_prepare, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *) c->in_a.p,
+                       (const int32_t *) c->in_b.p, (const int32_t *) c->in_c.p, I, T, (long long) count);
+    HIPCHK(hipGetLastError());
+    if (int r = mul_lists(c, P, I, T, count * kKpl * 2)) return r;
+    const long long n2 = (long long) count * 2 * kN;
+    hipLaunchKernelGGL(k_rows_sum<false>, dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, c->stream, (int32_t *) c->in_a.p,
+                       (const int32_t *) P, kKpl, (long long) count);  // tLweClear, then the rows in order
+    HIPCHK(hipGetLastError());
+    return d2h(c, acc, c->in_a.p, ab);
+}
+// tLweAddMulRTo (tlwe-functions.cpp:191-197): result[g] += p[g] * sample[g]
+int tfhe_hip_tlwe_addmul_r_batch(tfhe_hip_ctx *c, int32_t *result, const int32_t *poly, const int32_t *sample, int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || (count > 0 && (!result || !poly || !sample))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    const size_t ab = (size_t) count * 2 * kN * sizeof(int32_t);
+    if (int r = h2d(c, c->in_a, result, ab)) return r;
+    if (int r = h2d(c, c->in_b, sample, ab)) return r;
+    if (int r = h2d(c, c->in_c, poly, ab / 2)) return r;
+    HIPCHK(c->misc.reserve(2 * ab));
+    int32_t *I = (int32_t *) c->misc.p, *P = I + ab / 4;
+    const long long n1 = (long long) count * kN, n2 = (long long) count * 2 * kN;
+    hipLaunchKernelGGL(k_addmul_prepare, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *) c->in_c.p, I,
+                       (long long) count);
+    HIPCHK(hipGetLastError());
+    if (int r = mul_lists(c, P, I, (const int32_t *) c->in_b.p, count * 2)) return r;
+    hipLaunchKernelGGL(k_rows_sum<true>, dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, c->stream, (int32_t *) c->in_a.p,
+                       (const int32_t *) P, 1, (long long) count);
+    HIPCHK(hipGetLastError());
+    return d2h(c, result, c->in_a.p, ab);
 }
 
 // ---- client-side bulk operations --------------------------------------------------------------

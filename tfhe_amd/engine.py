@@ -69,6 +69,7 @@ EXPORTS = [
     "tfhe_hip_group_create", "tfhe_hip_group_destroy", "tfhe_hip_group_size", "tfhe_hip_group_ctx",
     "tfhe_hip_group_load_keys_coef", "tfhe_hip_group_load_keys_fft", "tfhe_hip_group_set_arithmetic",
     "tfhe_hip_group_gate_batch",
+    "tfhe_hip_tgsw_fft_extern_mul_batch", "tfhe_hip_tgsw_extern_mul_batch", "tfhe_hip_tlwe_addmul_r_batch",
 ]
 
 
@@ -427,6 +428,33 @@ class Engine:
         self._chk(self.lib.tfhe_hip_extern_mul_batch(self.ctx, _p(acc), _p(idx), ctypes.c_int64(acc.shape[0])),
                   "extern_mul_batch")
         return acc
+
+    def tgsw_fft_extern_mul(self, acc, gsw_fft, index):
+        """tGswFFTExternMulToTLwe with caller-supplied TGswSampleFFT operands [ngsw][2l][2][N/2][2]"""
+        P = self.params
+        acc = _i32(acc, (2, P.N)).copy()
+        g = np.ascontiguousarray(gsw_fft, dtype=np.float64).reshape(-1, P.kpl, 2, P.N // 2, 2)
+        idx = np.ascontiguousarray(index, dtype=np.int32).reshape(-1)
+        self._chk(self.lib.tfhe_hip_tgsw_fft_extern_mul_batch(self.ctx, _p(acc), _p(g), _p(idx), ctypes.c_int64(g.shape[0]),
+                                                              ctypes.c_int64(acc.shape[0])), "tgsw_fft_extern_mul_batch")
+        return acc
+
+    def tgsw_extern_mul(self, acc, tgsw, index):
+        """tGswExternMulToTLwe with caller-supplied coefficient-domain TGSW operands [ntgsw][2l][2][N]"""
+        P = self.params
+        acc = _i32(acc, (2, P.N)).copy()
+        g = _i32(tgsw, (P.kpl, 2, P.N))
+        idx = np.ascontiguousarray(index, dtype=np.int32).reshape(-1)
+        self._chk(self.lib.tfhe_hip_tgsw_extern_mul_batch(self.ctx, _p(acc), _p(g), _p(idx), ctypes.c_int64(g.shape[0]),
+                                                          ctypes.c_int64(acc.shape[0])), "tgsw_extern_mul_batch")
+        return acc
+
+    def tlwe_addmul_r(self, result, poly, sample):
+        P = self.params
+        res = _i32(result, (2, P.N)).copy()
+        self._chk(self.lib.tfhe_hip_tlwe_addmul_r_batch(self.ctx, _p(res), _p(_i32(poly, (P.N,))), _p(_i32(sample, (2, P.N))),
+                                                        ctypes.c_int64(res.shape[0])), "tlwe_addmul_r_batch")
+        return res
 
     def int_ifft(self, polys):
         return self._fwd(polys, self.lib.tfhe_hip_int_ifft_batch, "int_ifft_batch")
