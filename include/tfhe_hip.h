@@ -101,10 +101,14 @@ const char *tfhe_hip_last_error(void);
  *   FAST   the same negacyclic transforms in their minimal form (512 complex points in both directions, fused
  *          multiply-adds): decrypted bits identical, Torus32 coefficients within the tolerances of the reference's own
  *          tests - forward spectra |delta| <= 1e-10 (src/test/test-MulToTLwe.cpp:365-371), FFT products within 1 LSB of
- *          the exact product (src/test/test-multiplication.cpp:66-77), an external product within 4 LSB of the
- *          reference's, the phase of a bootstrapped sample within 2^22 LSB (2^-10) of the reference's; keyswitch and all
- *          integer stages stay exact.  About 1.6x the gate throughput.  Batches of up to 256 bootstraps run the latency
- *          kernel, which is exact arithmetic in both modes.
+ *          the exact product (src/test/test-multiplication.cpp:66-77), an external product and one CMux within 4 LSB of
+ *          the reference's; a bootstrapped sample carries noise of the reference's distribution (same rms, unbiased)
+ *          but not the reference's noise: after the first gadget digit that rounds differently the two accumulators
+ *          decorrelate, as for any two FFT implementations (tests/test_fast_mode.py).  Keyswitch and all integer
+ *          stages stay exact.  About 1.5x the gate throughput; a single gate in 2.2 ms instead of 3.0 ms.  Results are
+ *          deterministic and independent of the position in the batch, but batches of up to 512 bootstraps run the
+ *          latency kernel, which sums the 2l row products in another order than the throughput kernel: the same
+ *          input bootstrapped in a small and in a large batch may differ within the tolerances above.
  * The call waits for the context's stream; with keys loaded it derives the FAST key (a re-indexing of the same
  * doubles, 62 MB more device memory). */
 enum { TFHE_HIP_ARITH_EXACT = 0, TFHE_HIP_ARITH_FAST = 1 };

@@ -116,7 +116,7 @@ def test_integer_stages_stay_exact(fast, oracle, okeys):
 def test_blind_rotate_rotates_the_message(fast, keys, oracle):
     """src/test/bootstrapping_test_fft.cpp:99-144 with the real key, as for the exact mode: X^(sum s_i bara_i) * msg"""
     rng = np.random.default_rng(21)
-    cnt = 260                                                      # above the latency kernel's range: the FAST kernel
+    cnt = 520                                                      # above the latency kernel's range: the throughput kernel
     msg = rng.integers(-2**31, 2**31, (cnt, P.N)).astype(np.int32)
     acc = np.zeros((cnt, 2, P.N), np.int32)
     acc[:, 1] = msg
@@ -124,7 +124,7 @@ def test_blind_rotate_rotates_the_message(fast, keys, oracle):
     bara[1, :17] = 0
     out = fast.blind_rotate_batch(acc, bara)
     s = keys.tlwe_key.astype(np.int32)
-    for g in (0, 1, 259):
+    for g in (0, 1, 519):
         phase = out[g, 1].astype(np.int64) - oracle.mul_naive(s, out[g, 0]).astype(np.int64)
         shift = int((keys.lwe_key.astype(np.int64) * bara[g]).sum() % (2 * P.N))
         src = (np.arange(P.N) - shift) % (2 * P.N)
@@ -137,14 +137,14 @@ def test_one_cmux_within_4_lsb(fast, oracle, okeys):
     """a blind rotation with a single non-zero rotation amount = one CMux from identical inputs
     (tfhe_MuxRotate_FFT, lwe-bootstrapping-functions-fft.cpp:68-77)"""
     rng = np.random.default_rng(22)
-    cnt = 257
+    cnt = 513                                                      # the throughput kernel (the latency kernel: below)
     acc = rng.integers(-2**31, 2**31, (cnt, 2, P.N)).astype(np.int32)
     bara = np.zeros((cnt, P.n), np.int32)
     pos = rng.integers(0, P.n, cnt)
     bara[np.arange(cnt), pos] = rng.integers(1, 2 * P.N, cnt)
     out = fast.blind_rotate_batch(acc, bara)
     worst = 0
-    for g in (0, 1, 2, 128, 256):
+    for g in (0, 1, 2, 128, 512):
         worst = max(worst, int(np.abs(wrap(out[g].astype(np.int64) - oracle.blind_rotate(okeys, acc[g], bara[g]))).max()))
     assert worst <= 4, worst
 
@@ -177,9 +177,9 @@ def test_bootstrap_noise_matches_the_reference(fast, engine, oracle, okeys, clie
 
 @pytest.mark.parametrize("gate", list(Gate))
 def test_every_gate_truth_table(gate, fast, client, keys):
-    a = np.array([0, 1, 0, 1, 0, 1, 0, 1] * 40, np.uint8)          # 320 gates: the FAST kernel, not the latency kernel
-    b = np.array([0, 0, 1, 1, 0, 0, 1, 1] * 40, np.uint8)
-    c = np.array([0, 0, 0, 0, 1, 1, 1, 1] * 40, np.uint8)
+    a = np.array([0, 1, 0, 1, 0, 1, 0, 1] * 80, np.uint8)          # 640 gates: the throughput kernel, not the latency kernel
+    b = np.array([0, 0, 1, 1, 0, 0, 1, 1] * 80, np.uint8)
+    c = np.array([0, 0, 0, 0, 1, 1, 1, 1] * 80, np.uint8)
     ca, cb, cc = client.encrypt(keys, a, 31), client.encrypt(keys, b, 32), client.encrypt(keys, c, 33)
     got = fast.gate_batch(gate, ca, cb, cc)
     dec, phases = client.decrypt(keys, got)
@@ -205,8 +205,65 @@ def test_full_batch_16384_bits_identical(fast, engine, client, keys):
     print("output error rms 2^%.2f LSB (FAST) vs 2^%.2f (reference path)"
           % (np.log2(err.std()), np.log2(err_r.std())))
     assert 0.9 < err.std() / err_r.std() < 1.1
-    again = fast.gate_batch(Gate.NAND, ca[5000:5300], cb[5000:5300])       # deterministic and position independent
-    assert np.array_equal(again, got[5000:5300])                           # (within the FAST kernels: above 256 gates)
+    again = fast.gate_batch(Gate.NAND, ca[5000:5600], cb[5000:5600])       # deterministic and position independent
+    assert np.array_equal(again, got[5000:5600])                           # (within the throughput kernels: above 512 gates)
+
+
+def test_latency_kernel_one_cmux_within_4_lsb(fast, oracle, okeys):
+    """batches of up to 512 run the one-workgroup-per-ciphertext kernel (k_blind_rotate_coop_fast): the same folded
+    transforms, the six row products summed after the multiplication instead of accumulated by FMA"""
+    rng = np.random.default_rng(23)
+    cnt = 9
+    acc = rng.integers(-2**31, 2**31, (cnt, 2, P.N)).astype(np.int32)
+    bara = np.zeros((cnt, P.n), np.int32)
+    pos = rng.integers(0, P.n, cnt)
+    pos[0], pos[1] = 0, P.n - 1
+    bara[np.arange(cnt), pos] = rng.integers(1, 2 * P.N, cnt)
+    out = fast.blind_rotate_batch(acc, bara)
+    worst = 0
+    for g in range(cnt):
+        worst = max(worst, int(np.abs(wrap(out[g].astype(np.int64) - oracle.blind_rotate(okeys, acc[g], bara[g]))).max()))
+    assert worst <= 4, worst
+    none = fast.blind_rotate_batch(acc[:2], np.zeros((2, P.n), np.int32))   # no rotation at all: the accumulator comes back
+    assert np.array_equal(none, acc[:2])
+
+
+def test_latency_kernel_noise_and_bits(fast, engine, client, keys, monkeypatch):
+    """the latency kernel over 1,024 bootstraps (shape forced): identical bits, noise of the reference's distribution"""
+    from tfhe_amd import Engine
+    monkeypatch.setenv("TFHE_HIP_BR_WAVES", "6")
+    monkeypatch.setenv("TFHE_HIP_ARITH", "fast")
+    e = Engine(0)
+    try:
+        e.load_keys_coef(keys.bk_coef, keys.ks)
+        count = 1024
+        bits = np.random.default_rng(78).integers(0, 2, count).astype(np.uint8)
+        x = client.encrypt(keys, bits, seed=22)
+        got = e.bootstrap_batch(x, with_ks=False)
+        exact = engine.bootstrap_batch(x, with_ks=False)
+        b_f, ph_f = client.decrypt(keys, got, extracted=True)
+        b_e, ph_e = client.decrypt(keys, exact, extracted=True)
+        assert np.array_equal(b_f, bits) and np.array_equal(b_e, bits)
+        mu = np.where(bits == 1, 1 << 29, -(1 << 29)).astype(np.int64)
+        n_f, n_e = wrap(ph_f.astype(np.int64) - mu), wrap(ph_e.astype(np.int64) - mu)
+        rms = lambda v: float(np.sqrt((v.astype(np.float64) ** 2).mean()))  # noqa: E731
+        assert 0.9 < rms(n_f) / rms(n_e) < 1.1 and np.abs(n_f).max() < 2**27
+        assert abs(n_f.mean()) < 4 * rms(n_f) / np.sqrt(count)
+        assert np.array_equal(e.bootstrap_batch(x[100:103], with_ks=False), got[100:103])   # deterministic, position independent
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("gate", [Gate.NAND, Gate.XOR, Gate.ORYN, Gate.MUX])
+def test_latency_kernel_truth_tables(gate, fast, client, keys):
+    a = np.array([0, 1, 0, 1, 0, 1, 0, 1], np.uint8)               # 8 gates: the latency kernel
+    b = np.array([0, 0, 1, 1, 0, 0, 1, 1], np.uint8)
+    c = np.array([0, 0, 0, 0, 1, 1, 1, 1], np.uint8)
+    ca, cb, cc = client.encrypt(keys, a, 34), client.encrypt(keys, b, 35), client.encrypt(keys, c, 36)
+    got = fast.gate_batch(gate, ca, cb, cc)
+    dec, phases = client.decrypt(keys, got)
+    assert np.array_equal(dec, TRUTH[int(gate)](a.astype(np.int64), b.astype(np.int64), c.astype(np.int64)))
+    assert np.abs(np.abs(phases.astype(np.int64)) - (1 << 29)).max() < (1 << 28)
 
 
 @pytest.mark.parametrize("shape", ["1", "4", "8"])
@@ -218,7 +275,7 @@ def test_launch_shapes_agree(shape, keys, client, fast, monkeypatch):
     try:
         assert e.arithmetic == "fast"
         e.load_keys_coef(keys.bk_coef, keys.ks)
-        bits = np.random.default_rng(5).integers(0, 2, (3, 300)).astype(np.uint8)
+        bits = np.random.default_rng(5).integers(0, 2, (3, 600)).astype(np.uint8)
         ct = [client.encrypt(keys, bits[i], 40 + i) for i in range(3)]
         assert np.array_equal(e.gate_batch(Gate.MUX, *ct), fast.gate_batch(Gate.MUX, *ct))   # same arithmetic in every shape
     finally:
@@ -230,7 +287,7 @@ def test_switching_modes_on_one_context(keys, client, engine):
     e = Engine(0)
     try:
         e.load_keys_coef(keys.bk_coef, keys.ks)
-        bits = np.random.default_rng(6).integers(0, 2, (2, 400)).astype(np.uint8)
+        bits = np.random.default_rng(6).integers(0, 2, (2, 600)).astype(np.uint8)
         a, b = client.encrypt(keys, bits[0], 50), client.encrypt(keys, bits[1], 51)
         want = engine.gate_batch(Gate.XOR, a, b)
         assert np.array_equal(e.gate_batch(Gate.XOR, a, b), want)

@@ -48,6 +48,7 @@ constexpr int kKsT = 8, kKsBasebit = 2;
 #ifndef TFHE_HIP_KO
 #define TFHE_HIP_KO 0
 #endif
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct TwLds {  // this lane's column of the per-lane twiddle image in LDS (br_core.h: tw_slot_index)
     const c64 *t;  // image + lane
     __device__ __forceinline__ c64 operator()(int slot) const {
@@ -1017,6 +1018,275 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// latency shape in the FAST arithmetic mode: the same division of one ciphertext over one workgroup of 2l waves, with the
+// folded transforms of fast_core.h.  Per CMux, two workgroup barriers:
+//   every wave w:   digits of decomposition row w (from the prepared differences), forward transform, product with key
+//                   row w (both columns) into its LDS buffers                                            -> barrier
+//   waves 0 and 1:  sum of the 2l products of column 0 / 1, inverse transform (512 points, one wave: the folded inverse
+//                   is a quarter of the exact mode's work and is not split further), accumulator update, and - the
+//                   column being theirs alone - its rotated, prepared differences for the next CMux      -> barrier
+//   every wave:     key row w of the next CMux requested right after the first barrier (arrives during the inverse)
+// Rotations by 0 are skipped through a list of the non-zero rotation amounts built once per launch.  The twiddles of
+// both directions stay in registers (one ciphertext per CU: registers are not the constraint here).
+// LDS: twiddle image 24 KB | accumulator mirror 8 KB | per wave: products of column 0 (also the wave's transpose
+//      scratch) and column 1, 8 KB each | rotation list | prepared differences 8 KB
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kCoopFastWaves = kKpl + 2;  // 2l forward waves, one inverse wave per accumulator column
+constexpr int kCoopFastLds = brf::kFastLaneEntries * (int) sizeof(c64) + 2 * kN * 4 + kKpl * 2 * kNh * (int) sizeof(c64) +
+                             2 * 640 * 4 + 2 * kN * 4;
+static_assert(kCoopFastLds <= 160 * 1024, "LDS of one CU");
+#ifndef TFHE_HIP_COOP_TRACE
+#define TFHE_HIP_COOP_TRACE 0  // 1: per-phase clock totals of workgroup 0 on stdout (diagnostic build, tools/ko_build.sh)
+#endif
+// Prepared differences of one column: lane l holds, as four 16-byte words, the coefficients j = r<<6|l (quads 0, 1:
+// r = 0..3, 4..7) and j + 512 (quads 2, 3) - word (column * 4 + quad) * 64 + lane, conflict-free on either side.
+template <int MODE>
+__global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(BrArgs A) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
+    load_tw_to_lds(tw_lds, A.tw, brf::kFastLaneEntries);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    unsigned char *ptr = lds_raw + brf::kFastLaneEntries * sizeof(c64);
+    int32_t *acc = reinterpret_cast<int32_t *>(ptr);
+    c64 *bufs = reinterpret_cast<c64 *>(ptr + 2 * kN * 4);
+    const bool fwd_role = wave < kKpl;
+    const int ic = wave - kKpl;  // inverse role: accumulator column
+    c64 *mineA = bufs + (size_t) (fwd_role ? wave : 0) * 2 * kNh, *mineB = mineA + kNh;
+    int32_t *bara_lds = reinterpret_cast<int32_t *>(bufs + (size_t) kKpl * 2 * kNh);
+    int32_t *act = bara_lds + 640;                                   // (index << 16 | amount) of the non-zero rotations; [639] = count
+    uint32_t *diff = reinterpret_cast<uint32_t *>(act + 640);         // decomp_prepare((X^a - 1) * ACC), see diff_word
+    const long long g = blockIdx.x;  // host launches exactly B workgroups
+    const PhaseAConsts twu = A.ka;
+    const TwLds twl{tw_lds + lane};
+    const int c = wave >= kL ? 1 : 0, p = wave - c * kL;
+    constexpr int kThreads = 64 * kCoopFastWaves;
+
+    const int32_t *ga = nullptr, *gb = nullptr;
+    int32_t sa = A.sa, sb = A.sb, cst = A.cst;
+    const int32_t *gbara = nullptr;
+    if (MODE == MODE_GATE) {
+        ga = A.a + g * kCt;
+        gb = A.b ? A.b + g * kCt : nullptr;
+        if (A.jobs) {
+            const BrJob *j = A.jobs + g;
+            const int ia = __builtin_amdgcn_readfirstlane(j->ia), ib = __builtin_amdgcn_readfirstlane(j->ib);
+            sa = __builtin_amdgcn_readfirstlane(j->sa);
+            sb = __builtin_amdgcn_readfirstlane(j->sb);
+            cst = __builtin_amdgcn_readfirstlane(j->cst);
+            ga = A.a + (long long) ia * kCt;
+            gb = ib >= 0 ? A.a + (long long) ib * kCt : nullptr;
+        }
+    } else {
+        gbara = A.bara + g * kLwe;
+    }
+    auto comb = [&](int i) -> int32_t {
+        uint32_t t = (uint32_t) sa * (uint32_t) ga[i];
+        if (gb) t += (uint32_t) sb * (uint32_t) gb[i];
+        return (int32_t) t;
+    };
+    for (int i = threadIdx.x; i < kLwe; i += kThreads)
+        bara_lds[i] = MODE == MODE_GATE ? modswitch_2N(comb(i)) : (gbara[i] & (2 * kN - 1));
+    if (MODE == MODE_GATE) {
+        const int barb = modswitch_2N((int32_t) ((uint32_t) comb(kLwe) + (uint32_t) cst));
+        for (int j = threadIdx.x; j < kN; j += kThreads) {
+            acc[j] = 0;
+            acc[kN + j] = ((j + barb) & kN) ? (int32_t) (0u - (uint32_t) A.mu) : A.mu;
+        }
+    } else {
+        int32_t *io = A.acc_io + g * 2 * kN;
+        for (int j = threadIdx.x; j < 2 * kN; j += kThreads) acc[j] = io[j];
+    }
+    __syncthreads();
+    if (wave == 0) {  // a rotation by 0 is skipped (lwe-bootstrapping-functions-fft.cpp:154): list of the others, in order
+        int cnt = 0;
+        for (int base = 0; base < kLwe; base += 64) {
+            const int idx = base + lane;
+            const int a = idx < kLwe ? bara_lds[idx] : 0;
+            const unsigned long long m = __ballot(a != 0);
+            if (a != 0) act[cnt + __popcll(m & ((1ull << lane) - 1))] = (idx << 16) | a;
+            cnt += __popcll(m);
+        }
+        if (lane == 0) act[639] = cnt;
+    }
+    __syncthreads();
+    const int nact = __builtin_amdgcn_readfirstlane(act[639]);
+    int32_t own_lo[8], own_hi[8];  // inverse waves: coefficients j = r<<6|lane and j + 512 of accumulator column ic
+    if (!fwd_role) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            own_lo[r] = acc[ic * kN + ((r << 6) | lane)];
+            own_hi[r] = acc[ic * kN + ((r << 6) | lane) + kNh];
+        }
+    }
+    // inverse wave: rotated, prepared differences of its column for rotation amount a (the column's mirror must be current)
+    auto prepare_column = [&](int a) {
+        const int32_t *col = acc + ic * kN;
+        uint32_t d[16];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int j = (r << 6) | lane | (h << 9);
+                const int s = (j - a) & (2 * kN - 1);
+                const uint32_t v = (uint32_t) col[s & (kN - 1)];
+                const uint32_t rot = (s & kN) ? (0u - v) : v;
+                d[h * 8 + r] = decomp_prepare((int32_t) (rot - (uint32_t) (h ? own_hi[r] : own_lo[r])));
+            }
+        u32x4 *dq = reinterpret_cast<u32x4 *>(diff) + (ic * 4) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dq[q * 64] = u32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+    };
+    if (!fwd_role && nact > 0) prepare_column(__builtin_amdgcn_readfirstlane(act[0]) & 0xffff);
+    auto load_key_row = [&](c64 (&kb)[2][8], int it) {  // key row `wave` of TGSW sample `it` (Z_k order): 16 coalesced 1 KB loads
+        const c64 *row = A.bk + ((size_t) it * kKpl + wave) * 2 * kNh + lane;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) kb[c2][r] = row[c2 * kNh + r * 64];
+    };
+    c64 kb[2][8];
+    TwPre<8> twa;  // levels 3..8 of the role's transform
+    if (fwd_role) {
+        if (nact > 0) load_key_row(kb, __builtin_amdgcn_readfirstlane(act[0]) >> 16);
+        tw_preload(twa, twl, brf::FS_FB);
+    } else {
+        tw_preload(twa, twl, brf::FS_IB);
+    }
+    __syncthreads();
+#if TFHE_HIP_COOP_TRACE
+    long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp;
+#define TR(k) { const long long now = clock64(); tr[k] += now - tp; tp = now; }
+#else
+#define TR(k)
+#endif
+    // one loop per role (the roles never change: what one role keeps in registers is dead in the other's loop); both run
+    // the same two barriers per CMux
+    if (fwd_role) {
+#pragma unroll 1
+        for (int pos = 0; pos < nact; pos++) {
+#if TFHE_HIP_COOP_TRACE
+            tp = clock64();
+#endif
+            const int nxt = pos + 1 < nact ? __builtin_amdgcn_readfirstlane(act[pos + 1]) : 0;
+            c64 v[8];
+            {
+                const u32x4 *dq = reinterpret_cast<const u32x4 *>(diff) + (c * 4) * 64 + lane;
+                const u32x4 q0 = dq[0], q1 = dq[64], q2 = dq[128], q3 = dq[192];
+                const uint32_t lo[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                const uint32_t hi[8] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    v[r] = {(double) decomp_digit_rt(lo[br3(r)], p), (double) decomp_digit_rt(hi[br3(r)], p)};
+            }
+            TR(0)
+            brf::fwd_phaseA(v, twu);
+            t_write_A(mineA, v, lane);
+            wave_sync();
+            t_read_B(v, mineA, lane);
+            wave_sync();
+            brf::fwd_phaseBC<brf::FS_FB>(v, TwView<8, brf::FS_FB>{twa});
+            t_write_B(mineA, v, lane);
+            wave_sync();
+            t_read_C(v, mineA, lane);
+            wave_sync();
+            brf::fwd_phaseBC<brf::FS_FC>(v, TwView<8, brf::FS_FB>{twa});
+            TR(1)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {  // P_w = v * key row w
+                mineA[r * 64 + lane] = brf::cmul(v[r], kb[0][r]);
+                mineB[r * 64 + lane] = brf::cmul(v[r], kb[1][r]);
+            }
+            TR(2)
+            __syncthreads();  // all products in LDS; the forward waves are done with the differences
+            TR(3)
+            if (nxt) load_key_row(kb, nxt >> 16);  // arrives during the inverse transforms
+            __syncthreads();  // next differences in place; the inverse waves are done with the products
+            TR(3)
+        }
+    } else {
+#pragma unroll 1
+        for (int pos = 0; pos < nact; pos++) {
+#if TFHE_HIP_COOP_TRACE
+            tp = clock64();
+#endif
+            const int nxt = pos + 1 < nact ? __builtin_amdgcn_readfirstlane(act[pos + 1]) : 0;
+            __syncthreads();
+            TR(3)
+            c64 sp[8];
+            const c64 *src = bufs + ic * kNh + lane;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {  // the 2l products of four spectrum values at a time: 24 reads in flight
+                c64 u[4][kKpl];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int w = 0; w < kKpl; w++)  // the inverse wants Y_(br3(r)<<6|lane) in register r
+                        u[q][w] = src[(size_t) w * 2 * kNh + (br3(h * 4 + q) << 6)];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    sp[h * 4 + q] = u[q][0];
+#pragma unroll
+                    for (int w = 1; w < kKpl; w++) {
+                        sp[h * 4 + q].re += u[q][w].re;
+                        sp[h * 4 + q].im += u[q][w].im;
+                    }
+                }
+            }
+            TR(4)
+            // transpose scratch: a product buffer only this wave reads (column ic of forward wave 0)
+            c64 *iscr = ic ? mineB : mineA;
+            wave_sync();
+            brf::inv_phaseA(sp, twu);
+            t_write_A(iscr, sp, lane);
+            wave_sync();
+            t_read_B(sp, iscr, lane);
+            wave_sync();
+            brf::inv_phaseBC<brf::FS_IB>(sp, TwView<8, brf::FS_IB>{twa});
+            t_write_B(iscr, sp, lane);
+            wave_sync();
+            t_read_C(sp, iscr, lane);
+            TwPre<8> twb;  // untwist factors, requested ahead of the last three levels
+            tw_preload(twb, twl, brf::FS_IF);
+            wave_sync();
+            brf::inv_phaseBC<brf::FS_IC>(sp, TwView<8, brf::FS_IB>{twa});
+            int32_t lo[8], hi[8];
+            brf::inv_final<true>(lo, hi, sp, TwView<8, brf::FS_IF>{twb});
+            int32_t *dst = acc + ic * kN;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {  // tLweAddTo (tlwe-functions.cpp:149)
+                own_lo[r] = (int32_t) ((uint32_t) own_lo[r] + (uint32_t) lo[r]);
+                own_hi[r] = (int32_t) ((uint32_t) own_hi[r] + (uint32_t) hi[r]);
+                dst[(r << 6) | lane] = own_lo[r];
+                dst[((r << 6) | lane) + kNh] = own_hi[r];
+            }
+            TR(5)
+            if (nxt) {
+                wave_sync();
+                prepare_column(nxt & 0xffff);
+            }
+            TR(6)
+            __syncthreads();
+            TR(3)
+        }
+    }
+#if TFHE_HIP_COOP_TRACE
+    if (blockIdx.x == 0 && lane == 0)
+        printf("wave %d: digits %lld fwd %lld products %lld barriers %lld sum %lld inverse %lld prepare %lld\n", wave, tr[0], tr[1],
+               tr[2], tr[3], tr[4], tr[5], tr[6]);
+#endif
+#undef TR
+    if (MODE == MODE_GATE) {
+        int32_t *o = A.out + g * kExt;
+        for (int j = threadIdx.x; j < kN; j += kThreads) o[j] = j == 0 ? acc[0] : (int32_t) (0u - (uint32_t) acc[kN - j]);
+        if (threadIdx.x == 0) o[kN] = acc[kN];
+    } else {
+        int32_t *io = A.acc_io + g * 2 * kN;
+        for (int j = threadIdx.x; j < 2 * kN; j += kThreads) io[j] = acc[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // keyswitch: lweKeySwitch (lwe-keyswitch-functions.cpp:228-238) + lweKeySwitchTranslate_fromArray (:114-129)
 //   out = (0, b') - sum_{i<N, j<t} ks[i][j][digit_ij],  digit_ij = ((a'_i + 2^15) >> (30 - 2j)) & 3, digit 0 skipped
 // grid (ceil(B/G), 3), block 256: thread = one output coefficient q, G ciphertexts in registers.
@@ -1031,7 +1301,6 @@ __global__ __launch_bounds__(192) void k_keyswitch(const int32_t *__restrict__ i
     const int t = threadIdx.x;
     if (t >= kKsThreads) return;
     const long long g0 = (long long) blockIdx.x * kKsG;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 acc[kKsG];
 #pragma unroll
     for (int g = 0; g < kKsG; g++) {
@@ -1988,12 +2257,22 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0, const c64 *custom_bk = nullptr)
     // (measured, default set, ms for 256 / 512 / 768 / 1024 / 1536 gates: latency kernel 3.3 / 6.1 / 9.0 / 12.0 / 18.0,
     //  4 waves per workgroup 9.5 / 9.6 / 9.7 / 9.8 / 19.6, 8 waves 13.9 / 14.0 / 14.1 / 14.2 / 14.2; tools/shape_bench.py)
     constexpr long long kCoopMax = kCoopWaves > 4 ? 768 : 512;  // rounds of 256 workgroups that still beat 4 waves
-    // FAST mode: the latency kernel (exact arithmetic, valid in either mode) for one round of workgroups only; the
-    // four-wave FAST kernel overtakes it beyond that
-    const long long coop_max = c->arith == TFHE_HIP_ARITH_FAST ? 256 : kCoopMax;
+    // FAST mode (ms for 256 / 512 / 768 / 1024 gates, tools/lat_time.py: latency kernel 2.2 / 4.4 / 6.5 / 8.7, one wave
+    // per workgroup 5.6 / 6.0 / 6.3 / 6.4, four waves 6.4 / 6.4 / 6.5 / 6.5): two rounds of workgroups
+    const long long coop_max = c->arith == TFHE_HIP_ARITH_FAST ? 512 : kCoopMax;
     if (waves == 0)
         waves = MODE == MODE_EXTMUL ? (A.B <= 256 ? 1 : A.B <= 1024 ? 4 : 8)
                                     : (A.B <= coop_max ? kShapeCoop : A.B <= 1024 ? 4 : 8);
+    if (waves == kShapeCoop && MODE != MODE_EXTMUL && c->arith == TFHE_HIP_ARITH_FAST) {  // latency shape, FAST arithmetic
+        A.tw = c->twf;
+        A.bk = custom_bk ? custom_bk : c->bkf;
+        HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate_coop_fast<MODE == MODE_EXTMUL ? MODE_RAW : MODE>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kCoopFastLds));
+        hipLaunchKernelGGL((k_blind_rotate_coop_fast<MODE == MODE_EXTMUL ? MODE_RAW : MODE>), dim3((unsigned) A.B),
+                           dim3(64 * kCoopFastWaves), kCoopFastLds, c->stream, A);
+        HIPCHK(hipGetLastError());
+        return TFHE_HIP_OK;
+    }
     if (waves == kShapeCoop && MODE != MODE_EXTMUL) {  // one workgroup per ciphertext (latency shape)
         HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate_coop<MODE == MODE_EXTMUL ? MODE_RAW : MODE>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kCoopLds));
@@ -2004,7 +2283,7 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0, const c64 *custom_bk = nullptr)
     }
     if (waves == kShapeCoop) waves = 1;
     const bool fast = c->arith == TFHE_HIP_ARITH_FAST;
-    if (fast) {  // the image and the key of the mode (the latency kernel above is exact arithmetic in both modes)
+    if (fast) {  // the image and the key of the mode
         A.tw = c->twf;
         A.bk = c->bkf;
     }
