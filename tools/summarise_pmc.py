@@ -20,7 +20,7 @@ for p in ("fetch", "write", "sq1", "sq2", "tcc"):
     files = glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s" % (tag, p), "*", "*_counter_collection.csv"))
     if not files:
         continue
-    rows = list(csv.DictReader(open(files[0])))
+    rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))   # gpurun_out/ keeps earlier runs of the tag
     for key, short in names.items():
         mine = [r for r in rows if key + "<" in r["Kernel_Name"] or key + "(" in r["Kernel_Name"]]
         if not mine:
