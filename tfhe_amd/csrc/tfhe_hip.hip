@@ -1440,12 +1440,14 @@ __global__ __launch_bounds__(256, 2) void k_keyswitch_mfma(const uint32_t *__res
                                                         const int32_t *__restrict__ in, int32_t *__restrict__ out,
                                                         long long B, long long Bp, const KsJob *__restrict__ kj,
                                                         uint32_t *__restrict__ partial) {
-    // The key tile of a step (4 limbs x 1 KB) is fetched once per block - wave w brings limb w - and handed to the other
-    // waves through LDS (three tiles in rotation, one workgroup barrier per step); every wave reads the tile of step i+1
-    // into registers while its matrix instructions of step i run.  Before, every wave fetched every tile for itself:
-    // 72 B per clock and CU at the MFMA rate, more than the vector memory path of a CU delivers.
-    __shared__ v4i_t tile[3][4][64];
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // The key tiles (4 limbs x 1 KB per step) are fetched once per block - wave w brings limb w - and handed to the other
+    // waves through LDS, a GROUP of four steps at a time: two buffers of four tiles, ONE workgroup barrier per group.
+    // During group g a wave requests its limbs of group g+2 and, after the group's matrix instructions, writes those of
+    // group g+1 (requested one group earlier) into the other buffer; at the barrier that opens group g every wave has
+    // finished reading the buffer that is overwritten next, and the tiles written during group g-1 are visible.  The loop body has no branches (the last
+    // groups re-request and re-write the final group instead), so that the compiler can count its waits instead of
+    // draining the queues at block boundaries: one barrier and no drained wait per step took 1.47 -> see DESIGN.md 4.2.
+    __shared__ v4i_t tile[2][4][4][64];  // [buffer][step in group][limb][lane]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r32 = lane & 31, h = lane >> 5;
     const long long g0 = ((long long) blockIdx.x * 4 + wave) * (32 * kKsMT);
@@ -1460,54 +1462,63 @@ __global__ __launch_bounds__(256, 2) void k_keyswitch_mfma(const uint32_t *__res
         for (int m = 0; m < kKsMT; m++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[l][m][r] = 0;
-    const int i_per = kN / (int) gridDim.z, i_lo = (int) blockIdx.z * i_per, i_hi = i_lo + i_per;  // multiples of 4
+    const int i_per = kN / (int) gridDim.z, i_lo = (int) blockIdx.z * i_per;  // multiples of 64
+    const int groups = i_per / 4;                                             // >= 16
     auto key = [&](int i) { return bp[((size_t) i * 4 + wave) * kKsQ * 2]; };
-    tile[0][wave][lane] = key(i_lo);
-    tile[1][wave][lane] = key(i_lo + 1);
-    v4i_t gnext = key(i_lo + 2);  // in flight: the limb of step i + 2
-    __syncthreads();
-    v4i_t bcur[4], bnxt[4];
+    v4i_t gk[4];                 // this wave's limb of the four steps of a coming group
+    u32x4 a4[kKsMT], a4n[kKsMT];  // digit words of the current / next group (four steps each)
 #pragma unroll
-    for (int l = 0; l < 4; l++) bcur[l] = tile[0][l][lane];
-    u32x4 a4[kKsMT], a4n[kKsMT];
+    for (int ii = 0; ii < 4; ii++) tile[0][ii][wave][lane] = key(i_lo + ii);
+#pragma unroll
+    for (int ii = 0; ii < 4; ii++) gk[ii] = key(i_lo + 4 + ii);
 #pragma unroll
     for (int m = 0; m < kKsMT; m++) a4n[m] = ap[(size_t) (i_lo >> 2) * 64 + 32 * m];
 #pragma unroll 1
-    for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
+    for (int g = 0; g < groups; g++) {
+        const int buf = g & 1;
+        __syncthreads();
+        v4i_t b[2][4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) b[0][l] = tile[buf][0][l][lane];
+        // requests for later groups go out first and stay here (the scheduler otherwise sinks them to their uses)
+        const int ga = g + 1 < groups ? g + 1 : groups - 1;
 #pragma unroll
         for (int m = 0; m < kKsMT; m++) {
             a4[m] = a4n[m];
-            if (i0 + 4 < i_hi) a4n[m] = ap[(size_t) ((i0 + 4) >> 2) * 64 + 32 * m];
+            a4n[m] = ap[(size_t) ((i_lo >> 2) + ga) * 64 + 32 * m];
         }
+        v4i_t gk2[4];  // this wave's limb of group g + 2
+        const int gn = g + 2 < groups ? g + 2 : groups - 1;
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) gk2[ii] = key(i_lo + 4 * gn + ii);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
-            const int i = i0 + ii, s1 = (i - i_lo + 1) % 3, s2 = (i - i_lo + 2) % 3;
-            // tile of step i + 1 (complete since the last barrier) -> registers; the limb of step i + 2 -> LDS; request i + 3
-            if (i + 1 < i_hi) {
+            if (ii < 3) {
 #pragma unroll
-                for (int l = 0; l < 4; l++) bnxt[l] = tile[s1][l][lane];
+                for (int l = 0; l < 4; l++) b[(ii + 1) & 1][l] = tile[buf][ii + 1][l][lane];
             }
-            if (i + 2 < i_hi) tile[s2][wave][lane] = gnext;
-            if (i + 3 < i_hi) gnext = key(i + 3);
-            if (live) {
 #pragma unroll
-                for (int m = 0; m < kKsMT; m++) {
-                    const uint32_t ab = a4[m][ii];
-                    v4i_t a;
+            for (int m = 0; m < kKsMT; m++) {
+                const uint32_t ab = a4[m][ii];
+                v4i_t a;
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        // digit j = 4h + jj: ((ab >> (30 - 2j)) & 3); one-hot byte position = digit
-                        const uint32_t sh = (ab >> (27 - 2 * jj - 8 * h)) & 24u;
-                        a[jj] = (int) (1u << sh);
-                    }
-#pragma unroll
-                    for (int l = 0; l < 4; l++) acc[l][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bcur[l], acc[l][m], 0, 0, 0);
+                for (int jj = 0; jj < 4; jj++) {
+                    // digit j = 4h + jj: ((ab >> (30 - 2j)) & 3); one-hot byte position = digit
+                    const uint32_t sh = (ab >> (27 - 2 * jj - 8 * h)) & 24u;
+                    a[jj] = (int) (1u << sh);
                 }
-            }
-            __syncthreads();  // tile s2 is complete; nobody reads the tile of step i any more (it is written next at i + 1)
 #pragma unroll
-            for (int l = 0; l < 4; l++) bcur[l] = bnxt[l];
+                for (int l = 0; l < 4; l++)
+                    acc[l][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[ii & 1][l], acc[l][m], 0, 0, 0);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // tiles of group g + 1 (requested during group g - 1) into the buffer that group g - 1 was read from
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) tile[buf ^ 1][ii][wave][lane] = gk[ii];
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) gk[ii] = gk2[ii];
     }
     if (!live) return;
     if (q > kLwe) return;
@@ -2318,10 +2329,16 @@ struct KsWork {
 };
 // split of the input coefficients over block groups for a batch of Bp (padded) ciphertexts: fill the 256 CUs
 long long ks_xblocks(long long Bp) { return (Bp / (32 * kKsMT) + 3) / 4; }
+// ... and in whole rounds: the chip runs 512 blocks at a time (two per CU), so e.g. the 1,280 blocks of 16,384 ciphertexts
+// take three rounds for the work of 2.5; split two ways they are five rounds of half the length
 int ks_split(long long Bp) {
-    const long long xblocks = ks_xblocks(Bp);
+    const long long nb = kKsYB * ks_xblocks(Bp);
+    static const int forced = getenv("TFHE_HIP_KS_SPLIT") ? atoi(getenv("TFHE_HIP_KS_SPLIT")) : 0;  // diagnostic
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) return forced;
     int S = 1;
-    while (S < 16 && kKsYB * xblocks * S < 256) S *= 2;
+    while (S < 16 && nb * S < 256) S *= 2;
+    auto fill = [&](int s) { return (double) (nb * s) / (double) ((nb * s + 511) / 512 * 512); };
+    while (S < 16 && nb * S < 8192 && fill(S) < 0.9 && fill(2 * S) > fill(S)) S *= 2;
     return S;
 }
 int launch_ks(tfhe_hip_ctx *c, int32_t *d_out, const int32_t *d_in, long long B, const KsJob *kj = nullptr,
