@@ -155,6 +155,43 @@ def test_throughput_shape_on_a_full_batch(engine80, client80, keys80, oracle80, 
 
 
 @pytest.mark.gpu
+def test_fast_arithmetic_of_the_80_bit_library(engine80, client80, keys80, oracle80, okeys80):
+    """tfhe_hip_set_arithmetic(FAST) in the second build (l = 2: four forward waves in the latency kernel): one CMux
+    within 4 LSB of the oracle's in both kernels, gates decrypt to the truth table with the exact mode's noise level,
+    keyswitch still exact"""
+    from tfhe_amd import Engine
+    e = Engine(0, P)
+    try:
+        e.set_arithmetic("fast")
+        e.load_keys_coef(keys80.bk_coef, keys80.ks)
+        rng = np.random.default_rng(12)
+        wrap = lambda d: (np.asarray(d, np.int64) + 2**31) % 2**32 - 2**31  # noqa: E731
+        for cnt in (5, 520):                              # latency kernel | throughput kernel
+            acc = rng.integers(-2 ** 31, 2 ** 31, (cnt, 2, 1024), dtype=np.int64).astype(np.int32)
+            bara = np.zeros((cnt, P.n), np.int32)
+            bara[np.arange(cnt), rng.integers(0, P.n, cnt)] = rng.integers(1, 2048, cnt)
+            out = e.blind_rotate_batch(acc, bara)
+            for g in (0, 1, cnt - 1):
+                assert np.abs(wrap(out[g].astype(np.int64) - oracle80.blind_rotate(okeys80, acc[g], bara[g]))).max() <= 4
+        for m in (24, 1100):
+            bits = rng.integers(0, 2, (3, m)).astype(np.uint8)
+            a, b, c = (client80.encrypt(keys80, bits[i], seed=60 + i) for i in range(3))
+            for g in (Gate.NAND, Gate.MUX):
+                got = e.gate_batch(g, a, b, c if g == Gate.MUX else None)
+                dec, ph = client80.decrypt(keys80, got)
+                assert np.array_equal(dec, TRUTH[int(g)](bits[0], bits[1], bits[2])), (g, m)
+                assert np.abs(np.abs(ph.astype(np.int64)) - (1 << 29)).max() < (1 << 28)
+            if m == 1100:
+                err = np.abs(ph.astype(np.int64)) - (1 << 29)
+                ref = np.abs(client80.decrypt(keys80, engine80.gate_batch(Gate.MUX, a, b, c))[1].astype(np.int64)) - (1 << 29)
+                assert 0.85 < err.std() / ref.std() < 1.15
+        u = rng.integers(-2 ** 31, 2 ** 31, (70, 1025), dtype=np.int64).astype(np.int32)
+        assert np.array_equal(e.keyswitch_batch(u), engine80.keyswitch_batch(u))
+    finally:
+        e.close()
+
+
+@pytest.mark.gpu
 def test_client_side_kernels(engine80, client80, keys80):
     from tfhe_amd import Engine
     bits = np.random.default_rng(9).integers(0, 2, 777).astype(np.uint8)
