@@ -405,11 +405,18 @@ def main():
 
     client = Client(PR)
     # ---- keys: generated once (rank 0), replicated to every GPU by an RCCL broadcast -------------------------
-    from tfhe_amd.parallel import broadcast_keys
+    from tfhe_amd.parallel import broadcast_keys, broadcast_keys_device, broadcast_secret
     cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")   # collective tensors
-    keys = broadcast_keys(client.keygen(42) if rank == 0 else None, device=cdev, params=PR)
     eng = Engine(dev_index, PR)
-    eng.load_keys_coef(keys.bk_coef, keys.ks)
+    if world > 1 and os.environ.get("TFHE_BENCH_KEYS_VIA_HOST", "0") != "1":
+        # rank 0 loads and converts; its device-resident key buffers go straight into the other engines
+        keys = broadcast_secret(client.keygen(42) if rank == 0 else None, params=PR, device=cdev)
+        if rank == 0:
+            eng.load_keys_coef(keys.bk_coef, keys.ks)
+        broadcast_keys_device(eng)
+    else:
+        keys = broadcast_keys(client.keygen(42) if rank == 0 else None, device=cdev, params=PR)
+        eng.load_keys_coef(keys.bk_coef, keys.ks)
 
     # ---- synthetic inputs: fresh encryptions of iid random bits, resident in HBM -----------------------------
     B = args.batch

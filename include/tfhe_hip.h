@@ -123,6 +123,18 @@ int tfhe_hip_get_arithmetic(tfhe_hip_ctx *ctx);
  * Host pointers; the caller may free its copies afterwards. */
 int tfhe_hip_load_keys_coef(tfhe_hip_ctx *ctx, const int32_t *bk_coef, const int32_t *ks);
 int tfhe_hip_load_keys_fft(tfhe_hip_ctx *ctx, const double *bkfft, const int32_t *ks);
+
+/* Keys replicated by the caller's own transport - SURVEY.md 8(e): "once per key: RCCL ncclBroadcast of 61.9 MB + 82.7 MB" -
+ * between contexts of different processes (one process per GPU).  The reference has no counterpart beyond the per-call
+ * host-to-device copy of lwe-bootstrapping-functions-fft.cpp:112-133.
+ * tfhe_hip_keys_device_buffers: the context's three device-resident key buffers (bootstrapping key in the FFT domain,
+ *   keyswitch rows, keyswitch byte limbs), allocated if the context has none yet: ptrs[3], bytes[3].  On the rank that
+ *   loaded keys they hold them; on the others they are the destination of the broadcast (byte for byte; all ranks run
+ *   the same library build).
+ * tfhe_hip_keys_adopt: declares the buffers filled (the transport must have completed) - derives what the context's
+ *   arithmetic mode needs and marks the keys present.  Within one process use a device group instead. */
+int tfhe_hip_keys_device_buffers(tfhe_hip_ctx *ctx, void *ptrs[3], size_t bytes[3]);
+int tfhe_hip_keys_adopt(tfhe_hip_ctx *ctx);
 /* device copy of the FFT key back in the reference layout (parity check of the conversion) */
 int tfhe_hip_get_bkfft(tfhe_hip_ctx *ctx, double *bkfft_out);
 

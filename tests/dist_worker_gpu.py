@@ -16,15 +16,21 @@ def main(outdir):
     import torch.distributed as dist
     from tfhe_amd import Client, Engine, Gate, PARAMS as P
     from tfhe_amd.netlist import Netlist, full_adder_mux
-    from tfhe_amd.parallel import broadcast_keys, run_levels_sharded, sharded_gate_batch
+    from tfhe_amd.parallel import broadcast_keys_device, broadcast_secret, run_levels_sharded, sharded_gate_batch
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo")
     client = Client()
-    keys = broadcast_keys(client.keygen(42) if rank == 0 else None)
+    # rank 0 loads and converts the cloud keys; rank 1 receives only the secret part (to encrypt its inputs) and the
+    # three device-resident key buffers, and never sees the coefficient-domain keys
+    keys = broadcast_secret(client.keygen(42) if rank == 0 else None)
     eng = Engine(0)
-    eng.load_keys_coef(keys.bk_coef, keys.ks)
+    if rank == 0:
+        eng.load_keys_coef(keys.bk_coef, keys.ks)
+    else:
+        assert keys.bk_coef is None and keys.ks is None
+    broadcast_keys_device(eng)
     # a batch of independent gates, contiguous shards, all-gathered
     rng = np.random.default_rng(31)
     count = 1537

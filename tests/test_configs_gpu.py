@@ -117,6 +117,34 @@ def test_two_ranks_on_one_gpu(tmp_path, engine, client, keys):
         assert int(sum(int(v) << i for i, v in enumerate(b))) == int(xs[k] + ys[k])
 
 
+def test_key_buffers_adopted_from_another_context(engine, client, keys):
+    """tfhe_hip_keys_device_buffers / tfhe_hip_keys_adopt: a context that never saw the host keys takes over the three
+    device-resident key buffers of another one (here by plain device copies; tfhe_amd.parallel.broadcast_keys_device
+    moves the same buffers with a broadcast, covered by test_two_ranks_on_one_gpu) and computes the same ciphertexts"""
+    import ctypes
+    from tfhe_amd import Engine, TfheHipError
+    hip = ctypes.CDLL("libamdhip64.so")
+    e = Engine(0)
+    try:
+        with pytest.raises(TfheHipError):
+            e.adopt_keys()                                    # no buffers yet
+        engine.sync()
+        for (src, n1), (dst, n2) in zip(engine.key_buffers(), e.key_buffers()):
+            assert n1 == n2 and src != dst
+            assert hip.hipMemcpy(ctypes.c_void_p(dst), ctypes.c_void_p(src), ctypes.c_size_t(n1), 3) == 0   # device to device
+        bits = np.random.default_rng(3).integers(0, 2, (3, 700)).astype(np.uint8)
+        ct = [client.encrypt(keys, bits[i], 1500 + i) for i in range(3)]
+        with pytest.raises(TfheHipError):
+            e.gate_batch(Gate.NAND, ct[0], ct[1])             # filled but not adopted: still "keys not loaded"
+        e.adopt_keys()
+        assert np.array_equal(e.gate_batch(Gate.MUX, *ct), engine.gate_batch(Gate.MUX, *ct))
+        assert np.array_equal(e.gate_batch(Gate.NAND, ct[0][:3], ct[1][:3]), engine.gate_batch(Gate.NAND, ct[0][:3], ct[1][:3]))
+        e.set_arithmetic("fast")                              # the FAST key is derived from the adopted buffers
+        assert np.array_equal(client.decrypt(keys, e.gate_batch(Gate.XOR, ct[0], ct[1]))[0], bits[0] ^ bits[1])
+    finally:
+        e.close()
+
+
 def test_device_group_equals_single_context(engine, client, keys):
     """tfhe_hip_group_*: the C-level multi-GPU path (one context, stream and host thread per member, keys replicated
     device to device, contiguous shards).  The test box has one GPU, so the group is {0, 0, 0}: three contexts on it.

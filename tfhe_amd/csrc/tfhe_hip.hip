@@ -2566,6 +2566,29 @@ int tfhe_hip_load_keys_coef(tfhe_hip_ctx *c, const int32_t *bk_coef, const int32
     return keys_from_coef_in_misc(c, ks);
 }
 
+// Keys replicated by the caller's own transport (an RCCL broadcast between one-process-per-GPU ranks): the three
+// device-resident key buffers of a context, allocated here if it has none yet, and the call that declares them filled.
+int tfhe_hip_keys_device_buffers(tfhe_hip_ctx *c, void *ptrs[3], size_t bytes[3]) {
+    if (int r = check_ctx(c, false)) return r;
+    if (!ptrs || !bytes) return fail(TFHE_HIP_ERR_ARG, "null output array");
+    const size_t kl_bytes = (size_t) kN * 4 * kKsQ * 32;
+    if (!c->bk) HIPCHK(hipMalloc((void **) &c->bk, kBkBytes));
+    if (!c->ks) HIPCHK(hipMalloc((void **) &c->ks, kKsDevBytes));
+    if (!c->kl) HIPCHK(hipMalloc((void **) &c->kl, kl_bytes));
+    ptrs[0] = c->bk, ptrs[1] = c->ks, ptrs[2] = c->kl;
+    bytes[0] = kBkBytes, bytes[1] = kKsDevBytes, bytes[2] = kl_bytes;
+    return TFHE_HIP_OK;
+}
+int tfhe_hip_keys_adopt(tfhe_hip_ctx *c) {
+    if (int r = check_ctx(c, false)) return r;
+    if (!c->bk || !c->ks || !c->kl) return fail(TFHE_HIP_ERR_NOKEY, "no key buffers: call tfhe_hip_keys_device_buffers first");
+    c->have_keys = false;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (int r = build_fast_key(c)) return r;
+    c->have_keys = true;
+    return TFHE_HIP_OK;
+}
+
 }  // extern "C"
 namespace {
 // xoshiro256** state transition as a 256 x 256 matrix over GF(2), rows as 4 words: (M v)_i = parity(M[i] & v)

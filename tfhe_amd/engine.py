@@ -54,6 +54,7 @@ class TfheHipError(RuntimeError):
 _libs = {}
 
 EXPORTS = [
+    "tfhe_hip_keys_device_buffers", "tfhe_hip_keys_adopt",
     "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_load_keys_coef", "tfhe_hip_load_keys_fft",
     "tfhe_hip_get_bkfft", "tfhe_hip_gate_batch", "tfhe_hip_bootstrap_batch", "tfhe_hip_keyswitch_batch",
     "tfhe_hip_gate_batch_dev", "tfhe_hip_bootstrap_batch_dev", "tfhe_hip_keyswitch_batch_dev", "tfhe_hip_sync",
@@ -255,6 +256,16 @@ class Engine:
         assert bk.size == P.n * P.kpl * 2 * P.N
         k = _i32(ks, (P.N, P.ks_t, P.ks_base, P.n + 1))
         self._chk(self.lib.tfhe_hip_load_keys_fft(self.ctx, _p(bk), _p(k)), "load_keys_fft")
+
+    def key_buffers(self):
+        """[(device pointer, bytes)] of the three device-resident key buffers (allocated if absent): the source or the
+        destination of a key broadcast between ranks (tfhe_amd.parallel.broadcast_keys_device)"""
+        ptrs, sizes = (ctypes.c_void_p * 3)(), (ctypes.c_size_t * 3)()
+        self._chk(self.lib.tfhe_hip_keys_device_buffers(self.ctx, ptrs, sizes), "keys_device_buffers")
+        return [(int(ptrs[i]), int(sizes[i])) for i in range(3)]
+
+    def adopt_keys(self):
+        self._chk(self.lib.tfhe_hip_keys_adopt(self.ctx), "keys_adopt")
 
     def get_bkfft(self):
         P = self.params

@@ -2,8 +2,9 @@
 "gloo" in CPU tests).  The reference has no parallel code at all; what shards here is what is
 independent in the reference: the gates of one batch / one netlist level.
 
-  * keys are generated once and REPLICATED: one broadcast of the coefficient-domain bootstrapping key (31 MB) and the
-    keyswitch key (83 MB) from rank 0; every rank converts to the FFT domain on its own GPU,
+  * keys are generated once and REPLICATED: rank 0 loads and converts them, then its three device-resident key buffers
+    (62 MB FFT key, 62 + 84 MB keyswitch key) are broadcast straight into the other ranks' engines over RCCL
+    (broadcast_keys_device; broadcast_keys is the host-side form that the CPU tests use),
   * gates shard in contiguous blocks, no collective on the data path,
   * results are all-gathered only when the caller needs the whole array on every rank (next level of a netlist).
 """
@@ -46,6 +47,58 @@ def broadcast_keys(keys, device=None, src=0, params=None):
         dist.broadcast(t, src=src)
         parts[name] = t.cpu().numpy()
     return KeySet(int(seed.item()), **parts)
+
+
+class _DevBytes:
+    """zero-copy view of library-owned device memory for torch.as_tensor (uint8[nbytes])"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def broadcast_secret(keys, src=0, params=None, device=None):
+    """the small secret part of a KeySet (seed, LWE and TLWE keys) to every rank; cloud keys stay None elsewhere"""
+    P = params if params is not None else globals()["P"]
+    import torch
+    dist = _dist()
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return keys
+    dev = device if device is not None else torch.device("cpu")
+    t = torch.zeros(1 + P.n + P.N, dtype=torch.int64, device=dev)
+    if dist.get_rank() == src:
+        t[0] = keys.seed
+        t[1:1 + P.n] = torch.from_numpy(keys.lwe_key.astype(np.int64)).to(dev)
+        t[1 + P.n:] = torch.from_numpy(keys.tlwe_key.astype(np.int64)).to(dev)
+    dist.broadcast(t, src=src)
+    if dist.get_rank() == src:
+        return keys
+    h = t.cpu().numpy()
+    return KeySet(int(h[0]), h[1:1 + P.n].astype(np.int32), h[1 + P.n:].astype(np.int32), None, None)
+
+
+def broadcast_keys_device(engine, src=0):
+    """replicates the cloud keys of rank `src`'s engine (already loaded there) into every other rank's engine: one RCCL
+    broadcast per device-resident key buffer, no host copy and no second conversion (tfhe_hip_keys_device_buffers /
+    tfhe_hip_keys_adopt).  With a backend that takes no device tensors (gloo, the one-GPU rehearsal) the same buffers
+    are staged through the host."""
+    import torch
+    dist = _dist()
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    engine.sync()                                    # the engine's stream is not torch's
+    on_device = dist.get_backend() == "nccl"
+    for ptr, nbytes in engine.key_buffers():
+        t = torch.as_tensor(_DevBytes(ptr, nbytes), device=torch.device("cuda", torch.cuda.current_device()))
+        if on_device:
+            dist.broadcast(t, src=src)
+        else:
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            if dist.get_rank() != src:
+                t.copy_(h)
+    torch.cuda.synchronize()
+    if dist.get_rank() != src:
+        engine.adopt_keys()
 
 
 def all_gather_rows(local, count, device=None):
