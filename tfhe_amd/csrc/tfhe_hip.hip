@@ -13,6 +13,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the arithmetic contract of br_core.h forbids FMA
 // contraction).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
     //  to the row sum below: see DESIGN.md 4.1)
     constexpr int kCoopThreads = 64 * kCoopWaves;
     auto prepare_diff = [&](int a) {
-        constexpr int kIter = (2 * kN + kCoopThreads - 1) / kCoopThreads, kGroup = kIter > 6 ? kIter : 3;  // register room: four waves 8 of 8, six waves 3 of 6
+        constexpr int kIter = (2 * kN + kCoopThreads - 1) / kCoopThreads, kGroup = kIter;
 #pragma unroll
         for (int k0 = 0; k0 < kIter; k0 += kGroup) {
             uint32_t tmp[kGroup];
@@ -892,11 +893,17 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
 #pragma unroll
             for (int r = 0; r < 8; r++) kb[c2][r] = row[c2 * kNh + r * 64];
     };
+    // One loop per role - waves 0..3 transform forward AND run half an inverse transform, waves 4 and up only transform
+    // forward - with the role a compile-time constant: in a common loop the compiler has to keep what either role holds
+    // in registers alive through the other's code, runs at the register limit and serialises the LDS reads of the row
+    // sum behind their uses (see k_blind_rotate_coop_fast, where this was measured).
+    auto run = [&](auto inv_tag) {
+    constexpr bool INV = decltype(inv_tag)::value;
     c64 kb[2][8];
-    if (wave >= 4 && i < kLwe) load_key_row(kb, i);
+    if (!INV && i < kLwe) load_key_row(kb, i);
 #pragma unroll 1
     while (i < kLwe) {
-        if (wave < 4) load_key_row(kb, i);
+        if (INV) load_key_row(kb, i);
         c64 v[8];
         const uint32_t *dcol = diff + c * kN + lane;
 #pragma unroll
@@ -916,42 +923,31 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
         const int inext = next_active(i + 1);
         __syncthreads();  // all six products in LDS; every wave is done reading the differences
         // sum over the rows, in row order, by all threads: element e = (column, physical slot x)
-        if constexpr (kCoopWaves > 4) {  // six waves: no register room for more than one element at a time
-            for (int e = threadIdx.x; e < 2 * kNh; e += kCoopThreads) {
-                const int col = e >> 9, x = e & (kNh - 1);
-                const c64 *src = bufs + (size_t) col * kNh + x;
-                c64 t = src[0];
-#pragma unroll
-                for (int w = 1; w < kCoopWaves; w++) {
-                    const c64 u = src[(size_t) w * 2 * kNh];
-                    t.re += u.re;
-                    t.im += u.im;
-                }
-                *sum_slot(col, swz(x)) = t;
-            }
-        } else {  // four waves: all reads first, as in prepare_diff (2.28 -> 2.18 ms per gate)
-            constexpr int kIter = 2 * kNh / kCoopThreads;
+        {   // all reads first, as in prepare_diff
+            constexpr int kIter = (2 * kNh + kCoopThreads - 1) / kCoopThreads;
             c64 t[kIter];
 #pragma unroll
             for (int k = 0; k < kIter; k++) {
                 const int e = threadIdx.x + k * kCoopThreads;
-                const c64 *src = bufs + (size_t) (e >> 9) * kNh + (e & (kNh - 1));
-                t[k] = src[0];
+                if (e < 2 * kNh) {
+                    const c64 *src = bufs + (size_t) (e >> 9) * kNh + (e & (kNh - 1));
+                    t[k] = src[0];
 #pragma unroll
-                for (int w = 1; w < kCoopWaves; w++) {
-                    const c64 u = src[(size_t) w * 2 * kNh];
-                    t[k].re += u.re;
-                    t[k].im += u.im;
+                    for (int w = 1; w < kCoopWaves; w++) {
+                        const c64 u = src[(size_t) w * 2 * kNh];
+                        t[k].re += u.re;
+                        t[k].im += u.im;
+                    }
                 }
             }
 #pragma unroll
             for (int k = 0; k < kIter; k++) {
                 const int e = threadIdx.x + k * kCoopThreads;
-                *sum_slot(e >> 9, swz(e & (kNh - 1))) = t[k];
+                if (e < 2 * kNh) *sum_slot(e >> 9, swz(e & (kNh - 1))) = t[k];
             }
         }
         __syncthreads();  // summed spectra in place
-        if (wave >= 4) {  // (a branch of its own, so that the key registers are not live across the inverse transform)
+        if constexpr (!INV) {
             if (inext < kLwe) load_key_row(kb, inext);  // arrives during the inverse transforms
             __syncthreads();  // the same barrier as in the other branch
         } else {
@@ -1006,6 +1002,9 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
         i = inext;
         __syncthreads();  // next differences in place
     }
+    };
+    if (wave < 4) run(std::true_type{});
+    else run(std::false_type{});
 
     if (MODE == MODE_GATE) {
         int32_t *o = A.out + g * kExt;
