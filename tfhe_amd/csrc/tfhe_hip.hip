@@ -1717,30 +1717,34 @@ __global__ __launch_bounds__(256) void k_poly_mul(const int32_t *__restrict__ ip
     load_tw_to_lds(tw_lds, tw);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     c64 *scratch = reinterpret_cast<c64 *>(lds_raw + kTwLaneEntries * sizeof(c64)) + wave * kNh;
-    const long long poly = (long long) blockIdx.x * 4 + wave;
-    if (poly >= count) return;
     const PhaseAConsts twu = ka;
     const TwLds twl{tw_lds + lane};
-    c64 a[8], b[8], prod[8];
+    // a wave walks over products with the stride of the grid (the host launches at most a few workgroups per CU): the
+    // twiddle image is fetched once per workgroup, not once per four products
+#pragma unroll 1
+    for (long long poly = (long long) blockIdx.x * 4 + wave; poly < count; poly += (long long) gridDim.x * 4) {
+        c64 a[8], b[8], prod[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int j = (br3(r) << 6) | lane;
-        a[r] = {(double) ipolys[poly * kN + j], (double) ipolys[poly * kN + j + kNh]};
-        b[r] = {tpolys[poly * kN + j] * (1.0 / 4294967296.0), tpolys[poly * kN + j + kNh] * (1.0 / 4294967296.0)};
+        for (int r = 0; r < 8; r++) {
+            const int j = (br3(r) << 6) | lane;
+            a[r] = {(double) ipolys[poly * kN + j], (double) ipolys[poly * kN + j + kNh]};
+            b[r] = {tpolys[poly * kN + j] * (1.0 / 4294967296.0), tpolys[poly * kN + j + kNh] * (1.0 / 4294967296.0)};
+        }
+        wave_fwd(a, lane, scratch, twu, twl);
+        wave_fwd(b, lane, scratch, twu, twl);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {  // LagrangeHalfCPolynomialMul, polynomials.cpp:301-310
+            const double ac = a[r].re * b[r].re, bd = a[r].im * b[r].im, ad = a[r].re * b[r].im, bc = a[r].im * b[r].re;
+            prod[r] = {ac - bd, ad + bc};
+        }
+        c64 v[16];
+        int32_t res[16];
+        spectrum_to_inv_input(v, prod, lane, scratch);
+        wave_inv<false>(res, v, lane, scratch, twu, twl);
+#pragma unroll
+        for (int rho = 0; rho < 16; rho++) out[poly * kN + inv_yC(lane, rho)] = res[rho];
+        wave_sync();
     }
-    wave_fwd(a, lane, scratch, twu, twl);
-    wave_fwd(b, lane, scratch, twu, twl);
-#pragma unroll
-    for (int r = 0; r < 8; r++) {  // LagrangeHalfCPolynomialMul, polynomials.cpp:301-310
-        const double ac = a[r].re * b[r].re, bd = a[r].im * b[r].im, ad = a[r].re * b[r].im, bc = a[r].im * b[r].re;
-        prod[r] = {ac - bd, ad + bc};
-    }
-    c64 v[16];
-    int32_t res[16];
-    spectrum_to_inv_input(v, prod, lane, scratch);
-    wave_inv<false>(res, v, lane, scratch, twu, twl);
-#pragma unroll
-    for (int rho = 0; rho < 16; rho++) out[poly * kN + inv_yC(lane, rho)] = res[rho];
 }
 
 // ---- the same stages in the FAST arithmetic mode (fast_core.h); spectra cross the ABI in the reference order ----------
@@ -1802,26 +1806,30 @@ __global__ __launch_bounds__(256) void k_poly_mul_fast(const int32_t *__restrict
     load_tw_to_lds(tw_lds, tw, brf::kFastLaneEntries);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     c64 *scratch = reinterpret_cast<c64 *>(lds_raw + brf::kFastLaneEntries * sizeof(c64)) + wave * kNh;
-    const long long poly = (long long) blockIdx.x * 4 + wave;
-    if (poly >= count) return;
     const TwLds twl{tw_lds + lane};
-    c64 a[8], b[8];
+#pragma unroll 1
+    for (long long poly = (long long) blockIdx.x * 4 + wave; poly < count; poly += (long long) gridDim.x * 4) {  // as k_poly_mul
+        c64 a[8], b[8];   // (requesting the next product's operands ahead of the transforms measured no difference)
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int j = (br3(r) << 6) | lane;
-        a[r] = {(double) ipolys[poly * kN + j], (double) ipolys[poly * kN + j + kNh]};
-        b[r] = {tpolys[poly * kN + j] * (1.0 / 4294967296.0), tpolys[poly * kN + j + kNh] * (1.0 / 4294967296.0)};
-    }
-    wave_fwd_fast(a, lane, scratch, ka, twl);
-    wave_fwd_fast(b, lane, scratch, ka, twl);
+        for (int r = 0; r < 8; r++) {
+            const int j = (br3(r) << 6) | lane;
+            a[r] = {(double) ipolys[poly * kN + j], (double) ipolys[poly * kN + j + kNh]};
+            b[r] = {tpolys[poly * kN + j] * (1.0 / 4294967296.0), tpolys[poly * kN + j + kNh] * (1.0 / 4294967296.0)};
+        }
+        wave_fwd_fast(a, lane, scratch, ka, twl);
+        wave_sync();
+        wave_fwd_fast(b, lane, scratch, ka, twl);
+        wave_sync();
 #pragma unroll
-    for (int r = 0; r < 8; r++) a[r] = brf::cmul(a[r], b[r]);
-    int32_t lo[8], hi[8];
-    wave_inv_fast<false>(lo, hi, a, lane, scratch, ka, twl);
+        for (int r = 0; r < 8; r++) a[r] = brf::cmul(a[r], b[r]);
+        int32_t lo[8], hi[8];
+        wave_inv_fast<false>(lo, hi, a, lane, scratch, ka, twl);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        out[poly * kN + ((r << 6) | lane)] = lo[r];
-        out[poly * kN + ((r << 6) | lane) + kNh] = hi[r];
+        for (int r = 0; r < 8; r++) {
+            out[poly * kN + ((r << 6) | lane)] = lo[r];
+            out[poly * kN + ((r << 6) | lane) + kNh] = hi[r];
+        }
+        wave_sync();
     }
 }
 // bootstrapping key of the FAST mode from the exact mode's (physical slot x holds reference bin igray(x)): the same
@@ -2230,6 +2238,7 @@ constexpr size_t kBkBytes = (size_t) kLwe * kKpl * 2 * kNh * sizeof(c64);
 constexpr size_t kKsDevBytes = (size_t) kN * kKsT * 3 * kKsRow * sizeof(int32_t);
 constexpr size_t kKsHostElems = (size_t) kN * kKsT * 4 * kCt;
 constexpr int kFftLds = kTwLaneEntries * (int) sizeof(c64) + 4 * kNh * (int) sizeof(c64);
+constexpr long long kPolyMulMaxBlocks = 256 * 2 * 4;  // product kernels: workgroups walk over the batch (two resident per CU, four rounds)
 
 template <int MODE>
 int launch_br(tfhe_hip_ctx *c, const BrArgs &A0, const c64 *custom_bk = nullptr) {
@@ -3145,11 +3154,11 @@ int tfhe_hip_negacyclic_mul_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const int
     }
     if (c->arith == TFHE_HIP_ARITH_FAST) {
         HIPCHK(hipFuncSetAttribute((const void *) k_poly_mul_fast, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLdsFast));
-        hipLaunchKernelGGL(k_poly_mul_fast, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLdsFast, c->stream, d_i, d_t,
+        hipLaunchKernelGGL(k_poly_mul_fast, dim3((unsigned) std::min<long long>((count + 3) / 4, kPolyMulMaxBlocks)), dim3(256), kFftLdsFast, c->stream, d_i, d_t,
                            d_out, (const c64 *) c->twf, c->ka, (long long) count);
     } else {
         HIPCHK(hipFuncSetAttribute((const void *) k_poly_mul, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLds));
-        hipLaunchKernelGGL(k_poly_mul, dim3((unsigned) ((count + 3) / 4)), dim3(256), kFftLds, c->stream, d_i, d_t, d_out,
+        hipLaunchKernelGGL(k_poly_mul, dim3((unsigned) std::min<long long>((count + 3) / 4, kPolyMulMaxBlocks)), dim3(256), kFftLds, c->stream, d_i, d_t, d_out,
                            (const c64 *) c->tw, c->ka, (long long) count);
     }
     HIPCHK(hipGetLastError());
