@@ -160,9 +160,12 @@ def side_bench(args, torch, dev, rank, world):
         if args.workload == "fft":
             run = lambda: eng.negacyclic_mul_dev(d_out, a, b, B)  # noqa: E731
             flop, kernel = FLOP_PER_FFT_PRODUCT * B, "k_poly_mul%s" % ("_fast" if mode == "fast" else "")
-        else:   # N = 2048: four N = 1024 products per product (even/odd split), no reference transform exists
+        else:   # N = 2048 (no reference transform exists): even/odd split into N = 1024 transforms - FAST: one fused kernel,
+            # four forward + two inverse; EXACT: four separate N = 1024 products.  Algorithmic work in either mode: the
+            # minimal folded form at N = 2048, two forward + one inverse 1024-point transform + 1024 complex products
             run = lambda: eng.negacyclic_mul2048_dev(d_out, a, b, B)  # noqa: E731
-            flop, kernel = 4 * FLOP_PER_FFT_PRODUCT * B, "k_split2048 + k_poly_mul%s + k_combine2048" % ("_fast" if mode == "fast" else "")
+            flop = (3 * (1024 * 6 + 5 * 1024 * 10) + 1024 * 6.0) * B
+            kernel = "k_poly_mul2048_fast" if mode == "fast" else "k_split2048 + k_poly_mul + k_combine2048"
         unit, per_step, name = "products/s", B, "negacyclic IntPolynomial x TorusPolynomial FFT products/sec, N=%d" % n
     for _ in range(args.warmup):
         run()

@@ -80,11 +80,17 @@ def test_negacyclic_product_within_1_lsb_of_exact(fast, oracle):
     for i in range(a.shape[0]):
         assert np.abs(wrap(got[i].astype(np.int64) - oracle.mul_naive(a[i], b[i]))).max() <= 1    # :66-77
         assert np.abs(wrap(got[i].astype(np.int64) - oracle.mul_fft(a[i], b[i]))).max() <= 1
-    a2 = rng.integers(-4 * P.N, 4 * P.N, (3, 2 * P.N)).astype(np.int32)     # N = 2048: four N = 1024 products
-    b2 = rng.integers(-2**31, 2**31, (3, 2 * P.N)).astype(np.int32)
+    # N = 2048: one fused kernel (even/odd split summed in the evaluation domain: 4 forward + 2 inverse transforms);
+    # 9 products = more than the two waves... of one workgroup pass, with extreme operands among them
+    a2 = rng.integers(-4 * P.N, 4 * P.N, (9, 2 * P.N)).astype(np.int32)
+    b2 = rng.integers(-2**31, 2**31, (9, 2 * P.N)).astype(np.int32)
+    a2[1] = 4 * P.N - 1          # (constant a AND constant b = -2^31 would sum to 2^54, beyond any FP64 transform: 12 LSB)
+    a2[2], b2[2] = 0, 2**31 - 1
+    a2[3, 1:] = 0                                                            # a = a_0: the product is a_0 b
     got2 = fast.negacyclic_mul2048(a2, b2)
-    for i in range(3):
-        assert np.abs(wrap(got2[i].astype(np.int64) - oracle.mul_naive(a2[i], b2[i]))).max() <= 2
+    for i in range(9):
+        assert np.abs(wrap(got2[i].astype(np.int64) - oracle.mul_naive(a2[i], b2[i]))).max() <= 2, i
+    assert np.array_equal(got2[2], np.zeros(2 * P.N, np.int32))
 
 
 def test_key_is_the_reference_key(fast, oracle, okeys):

@@ -1832,6 +1832,69 @@ __global__ __launch_bounds__(256) void k_poly_mul_fast(const int32_t *__restrict
         wave_sync();
     }
 }
+// N = 2048 product in the FAST mode, one wave per product: with Y = X^2, a = a_e(Y) + X a_o(Y) in Z[Y]/(Y^1024 + 1),
+//   ab = (a_e b_e + Y a_o b_o)(Y) + X (a_e b_o + a_o b_e)(Y)
+// and the sums are taken in the evaluation domain: FOUR forward and TWO inverse transforms instead of the twelve of
+// four separate products, no operand lists and no second pass over the results.  Y evaluates to omega^(4k+1), which
+// is the twiddle of the last forward level (slots FS_FC+2, +3 and their quarter turns).  Even / odd coefficients
+// sit side by side in memory, so all loads and stores are 8 bytes per lane.
+__global__ __launch_bounds__(256) void k_poly_mul2048_fast(const int32_t *__restrict__ ipolys, const int32_t *__restrict__ tpolys,
+                                                           int32_t *__restrict__ out, const c64 *__restrict__ tw,
+                                                           PhaseAConsts ka, long long count) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    c64 *tw_lds = reinterpret_cast<c64 *>(lds_raw);
+    load_tw_to_lds(tw_lds, tw, brf::kFastLaneEntries);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    c64 *scratch = reinterpret_cast<c64 *>(lds_raw + brf::kFastLaneEntries * sizeof(c64)) + wave * kNh;
+    const TwLds twl{tw_lds + lane};
+    typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+    const c64 ta = twl(brf::FS_FC + 2), tb = twl(brf::FS_FC + 3);
+#pragma unroll 1
+    for (long long poly = (long long) blockIdx.x * 4 + wave; poly < count; poly += (long long) gridDim.x * 4) {
+        const i32x2 *pa = reinterpret_cast<const i32x2 *>(ipolys + poly * 2 * kN);
+        const i32x2 *pb = reinterpret_cast<const i32x2 *>(tpolys + poly * 2 * kN);
+        c64 ae[8], ao[8], be[8], bo[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int j = (br3(r) << 6) | lane;
+            const i32x2 a0 = pa[j], a1 = pa[j + kNh], b0 = pb[j], b1 = pb[j + kNh];
+            ae[r] = {(double) a0.x, (double) a1.x};
+            ao[r] = {(double) a0.y, (double) a1.y};
+            be[r] = {b0.x * (1.0 / 4294967296.0), b1.x * (1.0 / 4294967296.0)};
+            bo[r] = {b0.y * (1.0 / 4294967296.0), b1.y * (1.0 / 4294967296.0)};
+        }
+        wave_fwd_fast(ae, lane, scratch, ka, twl);
+        wave_sync();
+        wave_fwd_fast(ao, lane, scratch, ka, twl);
+        wave_sync();
+        wave_fwd_fast(be, lane, scratch, ka, twl);
+        wave_sync();
+        wave_fwd_fast(bo, lane, scratch, ka, twl);
+        wave_sync();
+        c64 se[8], so[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {  // register r holds Z_k, k = r<<6|lane: Y -> ta, tb, i ta, i tb, -ta, -tb, -i ta, -i tb
+            const c64 t0 = (r & 1) ? tb : ta;
+            const c64 t1 = (r & 2) ? c64{-t0.im, t0.re} : t0;
+            const c64 t = (r & 4) ? c64{-t1.re, -t1.im} : t1;
+            se[r] = brf::cmul(ae[r], be[r]);
+            brf::cmac(se[r], brf::cmul(ao[r], bo[r]), t);
+            so[r] = brf::cmul(ae[r], bo[r]);
+            brf::cmac(so[r], ao[r], be[r]);
+        }
+        int32_t le[8], he[8], lo[8], ho[8];
+        wave_inv_fast<false>(le, he, se, lane, scratch, ka, twl);
+        wave_sync();
+        wave_inv_fast<false>(lo, ho, so, lane, scratch, ka, twl);
+        i32x2 *po = reinterpret_cast<i32x2 *>(out + poly * 2 * kN);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            po[(r << 6) | lane] = i32x2{le[r], lo[r]};
+            po[((r << 6) | lane) + kNh] = i32x2{he[r], ho[r]};
+        }
+        wave_sync();
+    }
+}
 // bootstrapping key of the FAST mode from the exact mode's (physical slot x holds reference bin igray(x)): the same
 // doubles, re-indexed to Z_k order [poly][k] and conjugated where the fold asks for it - no arithmetic, so the key is
 // the reference's bkFFT bit for bit in both modes
@@ -3186,6 +3249,18 @@ int tfhe_hip_negacyclic_mul2048_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const
                                           int64_t count) {
     if (int r = check_ctx(c, false)) return r;
     if (count < 0 || (count > 0 && (!d_out || !d_i || !d_t))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (c->arith == TFHE_HIP_ARITH_FAST) {  // one fused kernel: four forward, two inverse transforms per product
+        if (count == 0) return TFHE_HIP_OK;
+        c->ev_br = c->ev_ks = false;
+        HIPCHK(hipEventRecord(c->ev[0], c->stream));
+        HIPCHK(hipFuncSetAttribute((const void *) k_poly_mul2048_fast, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLdsFast));
+        hipLaunchKernelGGL(k_poly_mul2048_fast, dim3((unsigned) std::min<long long>((count + 3) / 4, kPolyMulMaxBlocks)), dim3(256),
+                           kFftLdsFast, c->stream, d_i, d_t, d_out, (const c64 *) c->twf, c->ka, (long long) count);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev[1], c->stream));
+        c->ev_br = true;
+        return TFHE_HIP_OK;
+    }
     constexpr int64_t kChunk = 8192;  // workspace: 3 x 4 x 4 KB per product
     const int64_t first = count < kChunk ? count : kChunk;
     if (count > 0) HIPCHK(c->misc.reserve((size_t) first * 12 * kN * sizeof(int32_t)));
