@@ -475,7 +475,7 @@ def main():
                       "bad": int(ok_flag.item()), "noise_rms_log2": float(np.log2(noise.std())),
                       "noise_max_log2": float(np.log2(np.abs(noise).max() + 1))}
 
-    # per-gate latency: batch of 1 on one GPU (the latency kernel: exact arithmetic in either mode)
+    # per-gate latency: batch of 1 on one GPU (the latency kernel of the headline mode)
     lat_ms = None
     if rank == 0:
         eng.gate_batch_dev(Gate.NAND, d_out, d_a, d_b, None, count=1)
