@@ -411,3 +411,23 @@ def test_host_pipeline_error_leaves_the_context_usable(engine, client, keys, mon
         assert np.array_equal(client.decrypt(keys, out)[0], bits[0] | bits[1])
     finally:
         e2.close()
+
+
+def test_ragged_last_round_is_launched_on_its_own(engine, oracle, okeys, client, keys):
+    """2 x 2,048 + 100 gates: the remainder beyond whole rounds of the throughput shape runs as a launch of its own
+    (latency kernel); every row still equals the oracle's - sampled on both sides of the split - and decrypts"""
+    rng = np.random.default_rng(91)
+    count = 4096 + 100
+    bits = rng.integers(0, 2, (3, count)).astype(np.uint8)
+    ct = [client.encrypt(keys, bits[i], 900 + i) for i in range(3)]
+    out = engine.gate_batch(Gate.MUX, *ct)
+    dec, _ = client.decrypt(keys, out)
+    assert np.array_equal(dec, np.where(bits[0] == 1, bits[1], bits[2]))
+    pick = [0, 4095, 4096, 4097, count - 1]
+    want = oracle.gate_batch(okeys, Gate.MUX, ct[0][pick], ct[1][pick], ct[2][pick], nthreads=5)
+    assert np.array_equal(out[pick], want)
+    acc = rng.integers(-2**31, 2**31, (2048 + 3, 2, P.N)).astype(np.int32)      # the reference seam as well
+    bara = rng.integers(0, 2 * P.N, (2048 + 3, P.n)).astype(np.int32)
+    got = engine.blind_rotate_batch(acc, bara)
+    for g in (0, 2047, 2048, 2050):
+        assert np.array_equal(got[g], oracle.blind_rotate(okeys, acc[g], bara[g])), g

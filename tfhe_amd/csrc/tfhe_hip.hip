@@ -2333,6 +2333,29 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0, const c64 *custom_bk = nullptr)
         }
     } diag_print{c, A.B, d_diag};
 #endif
+    // A ragged last round: the chip holds 2,048 ciphertexts of the throughput shape at a time, and a round takes the same
+    // time however few of them it holds (37 gates beyond 16,384: + 9.4 ms).  A small remainder is launched on its own, in
+    // the shape that suits its size (up to 512: the latency kernel, 2.2 - 4.4 ms; up to 1,024: four waves, 6.5 ms).
+    constexpr long long kRound = 256 * 8;
+    if (c->br_waves == 0 && MODE != MODE_EXTMUL && A0.B > kRound && A0.B % kRound != 0 && A0.B % kRound <= 1024) {
+        BrArgs head = A0, tail = A0;
+        head.B = A0.B - A0.B % kRound;
+        tail.B = A0.B % kRound;
+        if (MODE == MODE_GATE) {
+            if (tail.jobs) {
+                tail.jobs += head.B;
+            } else {
+                tail.a += head.B * kCt;
+                if (tail.b) tail.b += head.B * kCt;
+            }
+            tail.out += head.B * kExt;
+        } else {
+            tail.acc_io += head.B * 2 * kN;
+            tail.bara += head.B * kLwe;
+        }
+        if (int r = launch_br<MODE>(c, head, custom_bk)) return r;
+        return launch_br<MODE>(c, tail, custom_bk);
+    }
     // waves per workgroup: 8 (two per SIMD) is the throughput shape.  Batches that cannot fill the chip that way run
     // with fewer waves per CU, which finish sooner (measured per wave: 8 per CU 16.4 ms, 4 per CU 10.5 ms, alone 8.8 ms)
     int waves = c->br_waves;
