@@ -1034,6 +1034,7 @@ constexpr int kCoopFastWaves = kKpl + 2;  // 2l forward waves, one inverse wave 
 constexpr int kCoopFastLds = brf::kFastLaneEntries * (int) sizeof(c64) + 2 * kN * 4 + kKpl * 2 * kNh * (int) sizeof(c64) +
                              2 * 640 * 4 + 2 * kN * 4;
 static_assert(kCoopFastLds <= 160 * 1024, "LDS of one CU");
+static_assert(kLwe < 639, "rotation list: 640 entries, the last one holds the count");
 #ifndef TFHE_HIP_COOP_TRACE
 #define TFHE_HIP_COOP_TRACE 0  // 1: per-phase clock totals of workgroup 0 on stdout (diagnostic build, tools/ko_build.sh)
 #endif
