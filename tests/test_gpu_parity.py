@@ -431,3 +431,20 @@ def test_ragged_last_round_is_launched_on_its_own(engine, oracle, okeys, client,
     got = engine.blind_rotate_batch(acc, bara)
     for g in (0, 2047, 2048, 2050):
         assert np.array_equal(got[g], oracle.blind_rotate(okeys, acc[g], bara[g])), g
+
+
+@pytest.mark.parametrize("cnt", [3, 600, 1100, 2100])
+def test_single_cmux_bit_exact(cnt, engine, oracle, okeys):
+    """tfhe_MuxRotate_FFT on its own (lwe-bootstrapping-functions-fft.cpp:68-77): a blind rotation with ONE non-zero
+    rotation amount is one CMux from the given accumulator - in the latency kernel (3), the one-wave-per-ciphertext
+    shapes (600, 1100) and the throughput shape with a ragged tail (2100); rotation amounts include 1, N and 2N - 1"""
+    rng = np.random.default_rng(100 + cnt)
+    acc = rng.integers(-2**31, 2**31, (cnt, 2, P.N)).astype(np.int32)
+    bara = np.zeros((cnt, P.n), np.int32)
+    pos = rng.integers(0, P.n, cnt)
+    amt = rng.integers(1, 2 * P.N, cnt)
+    pos[:3], amt[:3] = [0, P.n - 1, 314], [1, P.N, 2 * P.N - 1]
+    bara[np.arange(cnt), pos] = amt
+    got = engine.blind_rotate_batch(acc, bara)
+    for g in sorted({0, 1, 2, cnt // 2, cnt - 1}):
+        assert np.array_equal(got[g], oracle.blind_rotate(okeys, acc[g], bara[g])), g
