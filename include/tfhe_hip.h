@@ -151,6 +151,11 @@ int tfhe_hip_bootstrap_batch(tfhe_hip_ctx *ctx, int32_t *out, const int32_t *in,
 /* lweKeySwitch (lwe-keyswitch-functions.cpp:228): in[count][N+1] -> out[count][n+1] */
 int tfhe_hip_keyswitch_batch(tfhe_hip_ctx *ctx, int32_t *out, const int32_t *in, int64_t count);
 
+/* tGswTorus32PolynomialDecompH (tgsw-functions.cpp:297-331; the generic Torus32PolynomialDecompH_old, :277-293, with the
+ * library's l and Bgbit): polys[count][N] -> out[count][l][N], digits in [-Bg/2, Bg/2).  The stage the CMux applies to the
+ * rotated differences, on its own for parity checks and leveled circuits. */
+int tfhe_hip_tgsw_decomp_batch(tfhe_hip_ctx *ctx, int32_t *out, const int32_t *polys, int64_t count);
+
 /* ---- the same with every buffer already resident in device memory; asynchronous on the context's stream ---- */
 int tfhe_hip_gate_batch_dev(tfhe_hip_ctx *ctx, int gate, int32_t *d_out, const int32_t *d_a, const int32_t *d_b,
                             const int32_t *d_c, int64_t count);

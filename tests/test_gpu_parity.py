@@ -448,3 +448,23 @@ def test_single_cmux_bit_exact(cnt, engine, oracle, okeys):
     got = engine.blind_rotate_batch(acc, bara)
     for g in sorted({0, 1, 2, cnt // 2, cnt - 1}):
         assert np.array_equal(got[g], oracle.blind_rotate(okeys, acc[g], bara[g])), g
+
+
+def test_gadget_decomposition_equals_the_reference(engine, oracle):
+    """tGswTorus32PolynomialDecompH as a stage (tfhe_hip_tgsw_decomp_batch): the reference's own outputs
+    (tests/golden/primitives.npz), the oracle on random and extreme coefficients, and the reconstruction bound of
+    src/test/test-decomp-tgsw.cpp:72-79"""
+    import os
+    prim = np.load(os.path.join(os.path.dirname(__file__), "golden", "primitives.npz"))
+    assert np.array_equal(engine.decomp_batch(prim["torus_polys"][:prim["decomp"].shape[0]]), prim["decomp"])
+    rng = np.random.default_rng(17)
+    polys = rng.integers(-2**31, 2**31, (37, P.N)).astype(np.int32)
+    polys[0, :6] = [0, -1, 1, 2**31 - 1, -2**31, 1 << 10]
+    got = engine.decomp_batch(polys)
+    assert got.min() >= -64 and got.max() < 64
+    for i in (0, 1, 36):
+        assert np.array_equal(got[i], oracle.decomp(polys[i]))
+    rec = sum(got[:, p].astype(np.int64) << (32 - 7 * (p + 1)) for p in range(3))
+    err = (rec - polys.astype(np.int64) + 2**31) % 2**32 - 2**31
+    assert err.max() <= 0 and err.min() > -(1 << 11)     # the 11 dropped bits (the offset holds no rounding term)
+    assert engine.decomp_batch(polys[:0]).shape == (0, 3, P.N)

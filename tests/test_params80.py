@@ -265,3 +265,4 @@ def test_gpu_replays_the_reference_stages(stages80, engine80):
     assert np.array_equal(engine80.keyswitch_batch(g["ks_in"]), g["ks_out"])
     assert np.array_equal(engine80.get_bkfft()[g["extmul_index"]], g["bkfft_rows"])
     assert np.array_equal(engine80.extern_mul_batch(g["extmul_acc"], g["extmul_index"]), g["extmul_out"])
+    assert np.array_equal(engine80.decomp_batch(g["decomp_in"]), g["decomp_out"])     # Torus32PolynomialDecompH_old, l = 2, Bgbit = 10

@@ -1951,6 +1951,18 @@ __global__ __launch_bounds__(256) void k_combine2048(const int32_t *__restrict__
 // products run as one batch, and the rows are summed in integers - the same values in any order.
 // ---------------------------------------------------------------------------------------------------------------
 // products (g, p, c): I = digit (p % l) of column (p / l) of acc[g] (tGswTLweDecompH, tgsw-functions.cpp:264-270),
+// gadget decomposition as a stage of its own (tGswTorus32PolynomialDecompH, tgsw-functions.cpp:297-331): the same
+// decomp_prepare / decomp_digit that the CMux applies to the rotated differences.  out[poly][p][j]
+__global__ void k_decomp(int32_t *__restrict__ out, const int32_t *__restrict__ in, long long total) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long poly = i / kN;
+    const int j = (int) (i - poly * kN);
+    const uint32_t w = decomp_prepare(in[i]);
+#pragma unroll
+    for (int p = 0; p < kL; p++) out[(poly * kL + p) * kN + j] = decomp_digit(w, p);
+}
+
 // T = tgsw[index[g]][p][c]
 __global__ __launch_bounds__(256) void k_tgsw_prepare(const int32_t *__restrict__ acc, const int32_t *__restrict__ tgsw,
                                                       const int32_t *__restrict__ index, int32_t *__restrict__ I,
@@ -3156,6 +3168,20 @@ int tfhe_hip_keyswitch_batch(tfhe_hip_ctx *c, int32_t *out, const int32_t *in, i
     if (int r = h2d(c, c->in_a, in, ib)) return r;
     HIPCHK(c->outb.reserve(ob));
     if (int r = tfhe_hip_keyswitch_batch_dev(c, (int32_t *) c->outb.p, (const int32_t *) c->in_a.p, count)) return r;
+    return d2h(c, out, c->outb.p, ob);
+}
+
+int tfhe_hip_tgsw_decomp_batch(tfhe_hip_ctx *c, int32_t *out, const int32_t *polys, int64_t count) {
+    if (int r = check_ctx(c, false)) return r;
+    if (count < 0 || (count > 0 && (!out || !polys))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    if (count == 0) return TFHE_HIP_OK;
+    const size_t ib = (size_t) count * kN * sizeof(int32_t), ob = ib * kL;
+    if (int r = h2d(c, c->in_a, polys, ib)) return r;
+    HIPCHK(c->outb.reserve(ob));
+    const long long total = (long long) count * kN;
+    hipLaunchKernelGGL(k_decomp, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream, (int32_t *) c->outb.p,
+                       (const int32_t *) c->in_a.p, total);
+    HIPCHK(hipGetLastError());
     return d2h(c, out, c->outb.p, ob);
 }
 

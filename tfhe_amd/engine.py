@@ -54,7 +54,7 @@ class TfheHipError(RuntimeError):
 _libs = {}
 
 EXPORTS = [
-    "tfhe_hip_keys_device_buffers", "tfhe_hip_keys_adopt",
+    "tfhe_hip_keys_device_buffers", "tfhe_hip_keys_adopt", "tfhe_hip_tgsw_decomp_batch",
     "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_load_keys_coef", "tfhe_hip_load_keys_fft",
     "tfhe_hip_get_bkfft", "tfhe_hip_gate_batch", "tfhe_hip_bootstrap_batch", "tfhe_hip_keyswitch_batch",
     "tfhe_hip_gate_batch_dev", "tfhe_hip_bootstrap_batch_dev", "tfhe_hip_keyswitch_batch_dev", "tfhe_hip_sync",
@@ -256,6 +256,14 @@ class Engine:
         assert bk.size == P.n * P.kpl * 2 * P.N
         k = _i32(ks, (P.N, P.ks_t, P.ks_base, P.n + 1))
         self._chk(self.lib.tfhe_hip_load_keys_fft(self.ctx, _p(bk), _p(k)), "load_keys_fft")
+
+    def decomp_batch(self, polys):
+        """tGswTorus32PolynomialDecompH per polynomial: int32[count][N] -> int32[count][l][N]"""
+        P = self.params
+        x = np.ascontiguousarray(polys, dtype=np.int32).reshape(-1, P.N)
+        out = np.empty((x.shape[0], P.l, P.N), np.int32)
+        self._chk(self.lib.tfhe_hip_tgsw_decomp_batch(self.ctx, _p(out), _p(x), ctypes.c_int64(x.shape[0])), "tgsw_decomp_batch")
+        return out
 
     def key_buffers(self):
         """[(device pointer, bytes)] of the three device-resident key buffers (allocated if absent): the source or the
