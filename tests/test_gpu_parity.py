@@ -468,3 +468,29 @@ def test_gadget_decomposition_equals_the_reference(engine, oracle):
     err = (rec - polys.astype(np.int64) + 2**31) % 2**32 - 2**31
     assert err.max() <= 0 and err.min() > -(1 << 11)     # the 11 dropped bits (the offset holds no rounding term)
     assert engine.decomp_batch(polys[:0]).shape == (0, 3, P.N)
+
+
+def test_gpu_replays_the_reference_golden_vectors(engine, keys):
+    """the reference's own outputs (tests/golden/primitives.npz, bootstrap.npz, written by oracle/gen_golden.py from
+    /root/reference) against the GPU directly, with no oracle in between: the three transforms, the FFT product, key
+    conversion, external product, one CMux (tfhe_MuxRotate_FFT), whole blind rotations, bootstrap without and with
+    keyswitch, keyswitch on random samples"""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    prim, boot = np.load(os.path.join(gold, "primitives.npz")), np.load(os.path.join(gold, "bootstrap.npz"))
+    assert int(boot["key_seed"][0]) == keys.seed
+    assert np.array_equal(engine.int_ifft(prim["int_polys"]), prim["int_ifft"])          # IEEE doubles, compared exactly
+    assert np.array_equal(engine.torus_ifft(prim["torus_polys"]), prim["torus_ifft"])
+    assert np.array_equal(engine.torus_fft(prim["spectra"]), prim["torus_fft"])
+    assert np.array_equal(engine.negacyclic_mul(prim["mul_a"], prim["mul_b"]), prim["mul_fft"])
+    assert np.array_equal(engine.get_bkfft()[boot["bkfft_index"]], boot["bkfft_rows"])
+    assert np.array_equal(engine.extern_mul_batch(boot["extmul_acc"], boot["extmul_index"]), boot["extmul_out"])
+    bara = np.zeros((4, P.n), np.int32)
+    bara[np.arange(4), boot["extmul_index"]] = boot["mux_bara"]
+    keep = boot["mux_bara"] != 0                               # a rotation by 0 is no CMux at all in a blind rotation
+    assert np.array_equal(engine.blind_rotate_batch(boot["extmul_acc"], bara)[keep], boot["mux_out"][keep])
+    assert np.array_equal(engine.blind_rotate_batch(boot["br_acc"], boot["br_bara"]), boot["br_out"])
+    assert np.array_equal(engine.bootstrap_batch(boot["bs_in"], with_ks=False), boot["bs_woks"])
+    assert np.array_equal(engine.bootstrap_batch(boot["bs_in"], with_ks=True), boot["bs_out"])
+    assert np.array_equal(engine.keyswitch_batch(boot["bs_woks"]), boot["ks_out"])
+    assert np.array_equal(engine.keyswitch_batch(boot["ks_rand_in"]), boot["ks_rand_out"])
