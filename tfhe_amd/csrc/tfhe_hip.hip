@@ -3301,6 +3301,8 @@ int tfhe_hip_negacyclic_mul2048_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, const
     if (count < 0 || (count > 0 && (!d_out || !d_i || !d_t))) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
     if (c->arith == TFHE_HIP_ARITH_FAST) {  // one fused kernel: four forward, two inverse transforms per product
         if (count == 0) return TFHE_HIP_OK;
+        if ((((uintptr_t) d_out) | ((uintptr_t) d_i) | ((uintptr_t) d_t)) & 7)
+            return fail(TFHE_HIP_ERR_ARG, "N = 2048 polynomials must be 8-byte aligned");
         c->ev_br = c->ev_ks = false;
         HIPCHK(hipEventRecord(c->ev[0], c->stream));
         HIPCHK(hipFuncSetAttribute((const void *) k_poly_mul2048_fast, hipFuncAttributeMaxDynamicSharedMemorySize, kFftLdsFast));
