@@ -601,21 +601,24 @@ __device__ __forceinline__ void cmux_fast(int32_t *acc, c64 *scratch, int lane, 
     prio_exchange();
     t_write_A(scratch, xb, lane);
     wave_sync();
-    brf::inv_phaseBC<brf::FS_IB>(xa, twl);
+    TwPre<4> twib, twic;  // one read of the lane-dependent twiddles serves both transforms of the pair
+    tw_preload(twib, twl, brf::FS_IB);
+    brf::inv_phaseBC<brf::FS_IB>(xa, TwView<4, brf::FS_IB>{twib});
     prio_compute();
     t_read_B(xb, scratch, lane);
     wave_sync();
     prio_exchange();
     t_write_B(scratch, xa, lane);
     wave_sync();
-    brf::inv_phaseBC<brf::FS_IB>(xb, twl);
+    brf::inv_phaseBC<brf::FS_IB>(xb, TwView<4, brf::FS_IB>{twib});
     prio_compute();
     t_read_C(xa, scratch, lane);
     wave_sync();
     prio_exchange();
     t_write_B(scratch, xb, lane);
     wave_sync();
-    brf::inv_phaseBC<brf::FS_IC>(xa, twl);
+    tw_preload(twic, twl, brf::FS_IC);
+    brf::inv_phaseBC<brf::FS_IC>(xa, TwView<4, brf::FS_IC>{twic});
     {
         int32_t lo[8], hi[8];
         brf::inv_final<true>(lo, hi, xa, twl);
@@ -629,7 +632,7 @@ __device__ __forceinline__ void cmux_fast(int32_t *acc, c64 *scratch, int lane, 
     prio_compute();
     t_read_C(xb, scratch, lane);
     wave_sync();
-    brf::inv_phaseBC<brf::FS_IC>(xb, twl);
+    brf::inv_phaseBC<brf::FS_IC>(xb, TwView<4, brf::FS_IC>{twic});
     {
         int32_t lo[8], hi[8];
         brf::inv_final<true>(lo, hi, xb, twl);
