@@ -618,10 +618,12 @@ __device__ __forceinline__ void cmux_fast(int32_t *acc, c64 *scratch, int lane, 
     t_write_B(scratch, xb, lane);
     wave_sync();
     tw_preload(twic, twl, brf::FS_IC);
+    TwPre<8> twif;  // untwist factors, likewise read once for both
+    tw_preload(twif, twl, brf::FS_IF);
     brf::inv_phaseBC<brf::FS_IC>(xa, TwView<4, brf::FS_IC>{twic});
     {
         int32_t lo[8], hi[8];
-        brf::inv_final<true>(lo, hi, xa, twl);
+        brf::inv_final<true>(lo, hi, xa, TwView<8, brf::FS_IF>{twif});
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int j = (r << 6) | lane;
@@ -635,7 +637,7 @@ __device__ __forceinline__ void cmux_fast(int32_t *acc, c64 *scratch, int lane, 
     brf::inv_phaseBC<brf::FS_IC>(xb, TwView<4, brf::FS_IC>{twic});
     {
         int32_t lo[8], hi[8];
-        brf::inv_final<true>(lo, hi, xb, twl);
+        brf::inv_final<true>(lo, hi, xb, TwView<8, brf::FS_IF>{twif});
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int j = (r << 6) | lane;
