@@ -179,4 +179,48 @@ void harness_blind_rotate(void *p, int32_t *acc, const int32_t *bara) {
     free(s.a);
 }
 
+// an application that calls the reference's SINGLE-gate functions, one gate per call (the loop of
+// src/test/test-gate-bootstrapping.cpp:69-75): `fn` is the address of bootsXXX in whichever library provides it
+// (libtfhe_hip_gates.so in the tests); kind 0: (result, ca, cb, bk), 1: MUX (result, a, b, c, bk), 2: NOT / COPY
+// (result, ca, bk), 3: CONSTANT (result, value, bk) with value = count_or_value
+void harness_single_gates(void *p, void *fn, int kind, int32_t *out, const int32_t *a, const int32_t *b, const int32_t *c,
+                          int count, int value) {
+    Holder *h = (Holder *) p;
+    LweSample *r = new_samples(count, n), *sa = new_samples(count, n), *sb = new_samples(count, n),
+              *sc = new_samples(count, n);
+    for (int i = 0; i < count; i++) {
+        if (a) { memcpy(sa[i].a, a + (size_t) i * (n + 1), 4 * n); sa[i].b = a[(size_t) i * (n + 1) + n]; }
+        if (b) { memcpy(sb[i].a, b + (size_t) i * (n + 1), 4 * n); sb[i].b = b[(size_t) i * (n + 1) + n]; }
+        if (c) { memcpy(sc[i].a, c + (size_t) i * (n + 1), 4 * n); sc[i].b = c[(size_t) i * (n + 1) + n]; }
+    }
+    const TFheGateBootstrappingCloudKeySet *bk = &h->cloud;
+    typedef void (*bin_t)(LweSample *, const LweSample *, const LweSample *, const TFheGateBootstrappingCloudKeySet *);
+    typedef void (*mux_t)(LweSample *, const LweSample *, const LweSample *, const LweSample *, const TFheGateBootstrappingCloudKeySet *);
+    typedef void (*un_t)(LweSample *, const LweSample *, const TFheGateBootstrappingCloudKeySet *);
+    typedef void (*cst_t)(LweSample *, int32_t, const TFheGateBootstrappingCloudKeySet *);
+    for (int i = 0; i < count; i++) {
+        if (kind == 0) ((bin_t) fn)(&r[i], &sa[i], &sb[i], bk);
+        else if (kind == 1) ((mux_t) fn)(&r[i], &sa[i], &sb[i], &sc[i], bk);
+        else if (kind == 2) ((un_t) fn)(&r[i], &sa[i], bk);
+        else ((cst_t) fn)(&r[i], value, bk);
+    }
+    for (int i = 0; i < count; i++) {
+        memcpy(out + (size_t) i * (n + 1), r[i].a, 4 * n);
+        out[(size_t) i * (n + 1) + n] = r[i].b;
+    }
+    free_samples(sc, count); free_samples(sb, count); free_samples(sa, count); free_samples(r, count);
+}
+// the reference's seam under its own name (tfhe_blindRotate_FFT of libtfhe_hip_gates.so), through its address
+void harness_blind_rotate_fn(void *p, void *fn, int32_t *acc, const int32_t *bara) {
+    Holder *h = (Holder *) p;
+    typedef void (*seam_t)(TLweSample *, const TGswSampleFFT *, const int32_t *, const int32_t, const TGswParams *);
+    TLweSample s;
+    s.a = (TorusPolynomial *) malloc(2 * sizeof(TorusPolynomial));
+    s.b = s.a + 1; s.current_variance = 0; s.k = 1;
+    memcpy(s.a, acc, 2 * sizeof(TorusPolynomial));
+    ((seam_t) fn)(&s, h->bk, bara, n, &h->tgsw);
+    memcpy(acc, s.a, 2 * sizeof(TorusPolynomial));
+    free(s.a);
+}
+
 }  // extern "C"

@@ -138,3 +138,48 @@ def test_key_swapped_behind_the_same_pointer_is_noticed(keyset, client, oracle, 
         lib.harness_overwrite_keyset(h, P(np.ascontiguousarray(oracle.bkfft(okeys))), P(np.ascontiguousarray(keys.ks)))
     lib.harness_gate(h, int(Gate.NAND), P(out), P(ca), P(cb), None, 4)
     assert np.array_equal(out[2], oracle.gate(okeys, Gate.NAND, ca[2], cb[2]))
+
+
+GATES_LIB = os.path.join(ROOT, "tfhe_amd", "libtfhe_hip_gates.so")
+SINGLE = ["bootsNAND", "bootsOR", "bootsAND", "bootsXOR", "bootsXNOR", "bootsNOR", "bootsANDNY", "bootsANDYN", "bootsORNY",
+          "bootsORYN", "bootsMUX", "bootsNOT", "bootsCOPY", "bootsCONSTANT"]
+
+
+def test_gates_library_exports_the_reference_names():
+    """libtfhe_hip_gates.so: exactly the reference's single-gate entry points and its device seam
+    (src/include/tfhe_gate_bootstrapping_functions.h:44-87, src/include/tfhe.h:42), nothing else"""
+    out = subprocess.run(["nm", "-D", "--defined-only", GATES_LIB], check=True, capture_output=True, text=True).stdout
+    names = sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
+    assert names == sorted(SINGLE + ["tfhe_blindRotate_FFT"])
+
+
+@pytest.mark.gpu
+def test_single_gate_drop_ins_equal_the_batched_calls(keyset, client, keys, oracle, okeys):
+    """an unmodified gate-by-gate application (src/test/test-gate-bootstrapping.cpp:69-75) resolved against
+    libtfhe_hip_gates.so: every bootsXXX call = the batched shim with a batch of one = the oracle, bit for bit"""
+    from tests.truth import TRUTH
+    lib, h = keyset
+    gl = ctypes.CDLL(GATES_LIB)
+    a = np.array([0, 1, 0, 1], np.uint8)
+    b = np.array([0, 0, 1, 1], np.uint8)
+    c = np.array([1, 0, 0, 1], np.uint8)
+    ca, cb, cc = client.encrypt(keys, a, 41), client.encrypt(keys, b, 42), client.encrypt(keys, c, 43)
+    for gate, name in enumerate(SINGLE):
+        kind = 1 if name == "bootsMUX" else 2 if name in ("bootsNOT", "bootsCOPY") else 3 if name == "bootsCONSTANT" else 0
+        fn = ctypes.cast(getattr(gl, name), ctypes.c_void_p)
+        got, want = np.zeros((4, PR.n + 1), np.int32), np.zeros((4, PR.n + 1), np.int32)
+        lib.harness_single_gates(h, fn, kind, P(got), P(ca), P(cb), P(cc), 4, 1)
+        lib.harness_gate(h, gate, P(want), P(ca), P(cb), P(cc), 4)
+        assert np.array_equal(got, want), name
+        dec, _ = client.decrypt(keys, got)
+        assert np.array_equal(dec, TRUTH[gate](a.astype(np.int64), b.astype(np.int64), c.astype(np.int64))), name
+    assert np.array_equal(got[0][:PR.n], np.zeros(PR.n, np.int32))          # the last one was bootsCONSTANT(1): trivial sample
+    one = np.zeros((1, PR.n + 1), np.int32)
+    lib.harness_single_gates(h, ctypes.cast(gl.bootsXOR, ctypes.c_void_p), 0, P(one), P(ca[1:2]), P(cb[1:2]), None, 1, 0)
+    assert np.array_equal(one[0], oracle.gate(okeys, 3, ca[1], cb[1]))
+    rng = np.random.default_rng(8)
+    acc = rng.integers(-2**31, 2**31, (2, PR.N)).astype(np.int32)
+    bara = rng.integers(0, 2 * PR.N, PR.n).astype(np.int32)
+    got = acc.copy()
+    lib.harness_blind_rotate_fn(h, ctypes.cast(gl.tfhe_blindRotate_FFT, ctypes.c_void_p), P(got), P(bara))
+    assert np.array_equal(got, oracle.blind_rotate(okeys, acc, bara))

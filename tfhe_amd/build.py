@@ -51,6 +51,17 @@ def build_hip(force=False, lam=128):
     return out
 
 
+def build_gates(force=False, lam=128):
+    """libtfhe_hip_gates.so: the reference's own single-gate symbols (bootsNAND ...) forwarding to the GPU library"""
+    out = os.path.join(ROOT, "tfhe_amd", "libtfhe_hip_gates%s.so" % _suffix(lam))
+    src = os.path.join(CSRC, "gates_libtfhe.cpp")
+    if force or _stale(out, [src, os.path.join(ROOT, "include", "tfhe_hip_compat.h"), build_hip(False, lam)]):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-DTFHE_HIP_LAMBDA=%d" % lam,
+              "-I" + os.path.join(ROOT, "include"), "-o", out, src, "-L" + os.path.join(ROOT, "tfhe_amd"),
+              "-ltfhe_hip%s" % _suffix(lam), "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
 def build_client(force=False, lam=128):
     out = os.path.join(ROOT, "tfhe_amd", "libtfhe_client%s.so" % _suffix(lam))
     src = os.path.join(CSRC, "client_keys.c")
@@ -82,6 +93,7 @@ def build_test_harness(force=False):
 def build_all(force=False):
     for lam in LAMBDAS:
         build_hip(force, lam)
+        build_gates(force, lam)
         build_client(force, lam)
     build_oracle(force)
     build_test_harness(force)
