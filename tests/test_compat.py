@@ -183,3 +183,26 @@ def test_single_gate_drop_ins_equal_the_batched_calls(keyset, client, keys, orac
     got = acc.copy()
     lib.harness_blind_rotate_fn(h, ctypes.cast(gl.tfhe_blindRotate_FFT, ctypes.c_void_p), P(got), P(bara))
     assert np.array_equal(got, oracle.blind_rotate(okeys, acc, bara))
+
+
+REF_APP = os.path.join(ROOT, "oracle", "_ref", "ref_gate_app")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_APP + "_gpu"), reason="oracle/_ref applications not built (make -C oracle ref)")
+def test_reference_application_with_gates_from_the_gpu_library():
+    """oracle/ref_app.cpp - reference key generation (Gaussian noise, the reference's own generator), reference
+    encryption, a gate-by-gate circuit, reference decryption - built twice from the same source: linked against the
+    reference build alone, and with libtfhe_hip_gates.so ahead of it on the link line.  Same keys and inputs in both
+    runs (the reference's generator starts from its default seed): the fingerprint over all output ciphertexts must be
+    identical, i.e. the GPU gates are a drop-in on keys this repository did not generate"""
+    env = dict(os.environ, TFHE_HIP_ARITH="exact")
+    cpu = subprocess.run([REF_APP, "3"], check=True, capture_output=True, text=True, timeout=300).stdout.split()
+    gpu = subprocess.run([REF_APP + "_gpu", "3"], check=True, capture_output=True, text=True, timeout=300, env=env).stdout.split()
+    assert cpu[:3] == gpu[:3] and cpu[0] == "gates=18" and cpu[1] == "correct=18", (cpu, gpu)
+    ms = lambda w: float(w[3].split("=")[1])  # noqa: E731
+    print("reference application: %.1f ms per gate on the CPU, %.1f ms with the GPU gates" % (ms(cpu), ms(gpu)))
+    assert ms(gpu) < ms(cpu)
+    fast = subprocess.run([REF_APP + "_gpu", "3"], check=True, capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, TFHE_HIP_ARITH="fast")).stdout.split()
+    assert fast[:2] == cpu[:2] and fast[2] != cpu[2]          # FAST: same decrypted bits, other ciphertexts
