@@ -206,3 +206,25 @@ def test_reference_application_with_gates_from_the_gpu_library():
     fast = subprocess.run([REF_APP + "_gpu", "3"], check=True, capture_output=True, text=True, timeout=300,
                           env=dict(os.environ, TFHE_HIP_ARITH="fast")).stdout.split()
     assert fast[:2] == cpu[:2] and fast[2] != cpu[2]          # FAST: same decrypted bits, other ciphertexts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog", ["test-addition-boot", "test-gate-bootstrapping"])
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "test-addition-boot_gpu")),
+                    reason="oracle/_ref programs not built (make -C oracle ref)")
+def test_the_references_own_test_programs_run_on_the_gpu_gates(prog):
+    """src/test/test-addition-boot.cpp (4-bit full_adder_MUX, full_adder and comparison_MUX circuits, each verified by
+    decryption; it prints ERROR!!! on a wrong bit) and src/test/test-gate-bootstrapping.cpp, compiled UNMODIFIED from the
+    reference's sources: linked against the reference build alone and with libtfhe_hip_gates.so ahead of it.  The GPU
+    variant must verify like the CPU one and take less time for its circuits"""
+    import re
+    exe = os.path.join(ROOT, "oracle", "_ref", prog)
+    cpu = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=600).stdout
+    gpu = subprocess.run([exe + "_gpu"], check=True, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, TFHE_HIP_ARITH="exact")).stdout
+    assert "ERROR" not in cpu and "ERROR" not in gpu
+    t = lambda out: [float(x) for x in re.findall(r"microsecs\)\.\.\. ([0-9.]+)", out)]  # noqa: E731
+    assert len(t(cpu)) == len(t(gpu)) >= 1
+    print("%s, microseconds per timed section: CPU %s, GPU gates %s" % (prog, t(cpu), t(gpu)))
+    if len(t(gpu)) > 1:                                               # (the first timed section also creates the context and uploads the key)
+        assert sum(t(gpu)[1:]) < sum(t(cpu)[1:])
