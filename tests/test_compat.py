@@ -228,3 +228,24 @@ def test_the_references_own_test_programs_run_on_the_gpu_gates(prog):
     print("%s, microseconds per timed section: CPU %s, GPU gates %s" % (prog, t(cpu), t(gpu)))
     if len(t(gpu)) > 1:                                               # (the first timed section also creates the context and uploads the key)
         assert sum(t(gpu)[1:]) < sum(t(cpu)[1:])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "test-bootstrapping-fft_gpu")),
+                    reason="oracle/_ref programs not built (make -C oracle ref)")
+def test_the_references_bootstrap_program_through_the_seam():
+    """src/test/test-bootstrapping-fft.cpp, unmodified: it calls tfhe_bootstrap_FFT of the reference build, whose inner call
+    of tfhe_blindRotate_FFT (lwe-bootstrapping-functions-fft.cpp:203) resolves to libtfhe_hip_gates.so when that library
+    comes first - the reference's own device seam.  The phases it prints are functions of
+    every output coefficient: they must be the same text in both runs"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "test-bootstrapping-fft")
+    cpu = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=600).stdout
+    gpu = subprocess.run([exe + "_gpu"], check=True, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, TFHE_HIP_ARITH="exact")).stdout
+    phases = lambda out: [ln for ln in out.splitlines() if ln.startswith("phase")]  # noqa: E731
+    assert len(phases(cpu)) == 2 and phases(cpu) == phases(gpu), (cpu, gpu)
+    # ... and the seam really is this library's: with a device that does not exist the GPU variant dies in the shim
+    # (like die_dramatically), the CPU variant does not care
+    bad = dict(os.environ, TFHE_HIP_DEVICE="99", TFHE_HIP_DEVICES="")
+    assert subprocess.run([exe + "_gpu"], capture_output=True, text=True, timeout=600, env=bad).returncode != 0
+    assert subprocess.run([exe], capture_output=True, text=True, timeout=600, env=bad).returncode == 0
