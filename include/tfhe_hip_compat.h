@@ -111,6 +111,9 @@ void bootsCONSTANT_batch(LweSample *result, int32_t value, int32_t count, const 
  * first GPU of the default group; `bk` is uploaded on first use and whenever its fingerprint changes (rule above) */
 void tfhe_hip_blindRotate_FFT(TLweSample *accum, const TGswSampleFFT *bk, const int32_t *bara, const int32_t n,
                               const TGswParams *bk_params);
+/* tfhe_bootstrap_FFT (with_ks != 0) / tfhe_bootstrap_woKS_FFT (with_ks == 0) of src/include/tfhe.h:44-45 on the
+ * reference's structs: one sample, first GPU of the default group; key caching rule as above (owner = bk) */
+void tfhe_hip_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, int32_t mu, const LweSample *x, int with_ks);
 /* releases the default group and its cached key (optional; for tests and orderly shutdown) */
 void tfhe_hip_default_context_reset(void);
 

@@ -223,4 +223,21 @@ void harness_blind_rotate_fn(void *p, void *fn, int32_t *acc, const int32_t *bar
     free(s.a);
 }
 
+// tfhe_bootstrap_FFT / tfhe_bootstrap_woKS_FFT under their own names (src/include/tfhe.h:44-45), through their address:
+// `count` samples one call at a time; out rows have n + 1 (with keyswitch) or N + 1 entries
+void harness_bootstrap_fn(void *p, void *fn, int with_ks, int32_t *out, const int32_t *in, int32_t mu, int count) {
+    Holder *h = (Holder *) p;
+    typedef void (*boot_t)(LweSample *, const LweBootstrappingKeyFFT *, int32_t, const LweSample *);
+    const int dim = with_ks ? n : N;
+    LweSample *r = new_samples(count, dim), *x = new_samples(count, n);
+    for (int i = 0; i < count; i++) {
+        memcpy(x[i].a, in + (size_t) i * (n + 1), 4 * n);
+        x[i].b = in[(size_t) i * (n + 1) + n];
+        ((boot_t) fn)(&r[i], &h->bkfft, mu, &x[i]);
+        memcpy(out + (size_t) i * (dim + 1), r[i].a, 4 * dim);
+        out[(size_t) i * (dim + 1) + dim] = r[i].b;
+    }
+    free_samples(x, count); free_samples(r, count);
+}
+
 }  // extern "C"

@@ -150,7 +150,7 @@ def test_gates_library_exports_the_reference_names():
     (src/include/tfhe_gate_bootstrapping_functions.h:44-87, src/include/tfhe.h:42), nothing else"""
     out = subprocess.run(["nm", "-D", "--defined-only", GATES_LIB], check=True, capture_output=True, text=True).stdout
     names = sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
-    assert names == sorted(SINGLE + ["tfhe_blindRotate_FFT"])
+    assert names == sorted(SINGLE + ["tfhe_blindRotate_FFT", "tfhe_bootstrap_FFT", "tfhe_bootstrap_woKS_FFT"])
 
 
 @pytest.mark.gpu
@@ -183,6 +183,14 @@ def test_single_gate_drop_ins_equal_the_batched_calls(keyset, client, keys, orac
     got = acc.copy()
     lib.harness_blind_rotate_fn(h, ctypes.cast(gl.tfhe_blindRotate_FFT, ctypes.c_void_p), P(got), P(bara))
     assert np.array_equal(got, oracle.blind_rotate(okeys, acc, bara))
+    # tfhe_bootstrap_FFT / tfhe_bootstrap_woKS_FFT (src/include/tfhe.h:44-45), one sample per call
+    x = client.encrypt(keys, np.array([1, 0, 1], np.uint8), 44)
+    full, woks = np.zeros((3, PR.n + 1), np.int32), np.zeros((3, PR.N + 1), np.int32)
+    lib.harness_bootstrap_fn(h, ctypes.cast(gl.tfhe_bootstrap_FFT, ctypes.c_void_p), 1, P(full), P(x), 1 << 29, 3)
+    lib.harness_bootstrap_fn(h, ctypes.cast(gl.tfhe_bootstrap_woKS_FFT, ctypes.c_void_p), 0, P(woks), P(x), 1 << 29, 3)
+    for i in range(3):
+        assert np.array_equal(woks[i], oracle.bootstrap_woks(okeys, x[i]))
+        assert np.array_equal(full[i], oracle.keyswitch(okeys, woks[i]))
 
 
 REF_APP = os.path.join(ROOT, "oracle", "_ref", "ref_gate_app")
@@ -234,10 +242,11 @@ def test_the_references_own_test_programs_run_on_the_gpu_gates(prog):
 @pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "test-bootstrapping-fft_gpu")),
                     reason="oracle/_ref programs not built (make -C oracle ref)")
 def test_the_references_bootstrap_program_through_the_seam():
-    """src/test/test-bootstrapping-fft.cpp, unmodified: it calls tfhe_bootstrap_FFT of the reference build, whose inner call
-    of tfhe_blindRotate_FFT (lwe-bootstrapping-functions-fft.cpp:203) resolves to libtfhe_hip_gates.so when that library
-    comes first - the reference's own device seam.  The phases it prints are functions of
-    every output coefficient: they must be the same text in both runs"""
+    """src/test/test-bootstrapping-fft.cpp, unmodified: its calls of tfhe_bootstrap_FFT (src/include/tfhe.h:45) resolve to
+    libtfhe_hip_gates.so when that library comes first - the whole bootstrap on the GPU.  (Were only the seam replaced,
+    the reference's tfhe_bootstrap_FFT would reach this library through its inner call of tfhe_blindRotate_FFT,
+    lwe-bootstrapping-functions-fft.cpp:203: the relocation is a PLT slot, and that is how the first version of this test
+    ran.)  The phases it prints must be the same text in both runs"""
     exe = os.path.join(ROOT, "oracle", "_ref", "test-bootstrapping-fft")
     cpu = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=600).stdout
     gpu = subprocess.run([exe + "_gpu"], check=True, capture_output=True, text=True, timeout=600,

@@ -257,6 +257,26 @@ void tfhe_hip_blindRotate_FFT(TLweSample *accum, const TGswSampleFFT *bk, const 
     for (int c = 0; c < 2; c++) std::memcpy(accum->a[c].coefsT, acc.data() + c * kN, sizeof(int32_t) * kN);
 }
 
+// tfhe_bootstrap_FFT / tfhe_bootstrap_woKS_FFT (lwe-bootstrapping-functions-fft.cpp:266, :222) on the reference's structs:
+// ONE sample on the first GPU of the default group; with_ks == 0 leaves the LWE_N sample (result->a has N entries)
+void tfhe_hip_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, int32_t mu, const LweSample *x, int with_ks) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    tfhe_hip_group *grp = default_group_locked();
+    if (!result || !x || !bk || !bk->bkFFT || !bk->ks) die("tfhe_hip_bootstrap_FFT: null argument");
+    if (bk->in_out_params->n != kn || bk->accum_params->N != kN || bk->accum_params->k != 1 ||
+        bk->bk_params->l != TFHE_HIP_L || bk->bk_params->Bgbit != TFHE_HIP_BGBIT)
+        die("bootstrapping key of another parameter set");
+    ensure_keys_locked(grp, bk, bk->bkFFT, bk->ks);
+    std::vector<int32_t> in(kn + 1), out(kN + 1);
+    std::memcpy(in.data(), x->a, sizeof(int32_t) * kn);
+    in[kn] = x->b;
+    if (tfhe_hip_bootstrap_batch(tfhe_hip_group_ctx(grp, 0), out.data(), in.data(), mu, 1, with_ks) != 0) die("bootstrap");
+    const int dim = with_ks ? kn : kN;
+    std::memcpy(result->a, out.data(), sizeof(int32_t) * dim);
+    result->b = out[dim];
+    result->current_variance = 0.;
+}
+
 int tfhe_hip_group_gate_batch_samples(tfhe_hip_group *group, int gate, LweSample *result, const LweSample *a,
                                       const LweSample *b, const LweSample *c, int32_t count) {
     if (!group || count < 0 || (count > 0 && !result)) return TFHE_HIP_ERR_ARG;

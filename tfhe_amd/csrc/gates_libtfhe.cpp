@@ -1,6 +1,7 @@
 // libtfhe_hip_gates.so: the reference's OWN single-gate entry points - bootsNAND ... bootsMUX, bootsNOT, bootsCOPY,
-// bootsCONSTANT (src/include/tfhe_gate_bootstrapping_functions.h:44-87, defined in src/libtfhe/boot-gates.cpp) and the
-// device seam tfhe_blindRotate_FFT (src/include/tfhe.h:42) - with their exact names and signatures, each forwarding
+// bootsCONSTANT (src/include/tfhe_gate_bootstrapping_functions.h:44-87, defined in src/libtfhe/boot-gates.cpp), the
+// bootstraps tfhe_bootstrap_FFT / tfhe_bootstrap_woKS_FFT and the device seam tfhe_blindRotate_FFT
+// (src/include/tfhe.h:42-45) - with their exact names and signatures, each forwarding
 // to the batched shim with a batch of one ("single-gate bootsNAND etc. forward to batch of 1").
 //
 // A separate library on purpose: these names are libtfhe's.  An application that still links libtfhe for key
@@ -46,4 +47,13 @@ TFHE_HIP_EXPORT void bootsCONSTANT(LweSample *result, int32_t value, const TFheG
 TFHE_HIP_EXPORT void tfhe_blindRotate_FFT(TLweSample *accum, const TGswSampleFFT *bk, const int32_t *bara, const int32_t n,
                                           const TGswParams *bk_params) {
     tfhe_hip_blindRotate_FFT(accum, bk, bara, n, bk_params);
+}
+// lwe-bootstrapping-functions-fft.cpp:266 and :222 - the whole bootstrap (modulus switch, blind rotation, extraction, and
+// for the first one the keyswitch) instead of the seam alone
+TFHE_HIP_EXPORT void tfhe_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, int32_t mu, const LweSample *x) {
+    tfhe_hip_bootstrap_FFT(result, bk, mu, x, 1);
+}
+TFHE_HIP_EXPORT void tfhe_bootstrap_woKS_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, int32_t mu,
+                                             const LweSample *x) {
+    tfhe_hip_bootstrap_FFT(result, bk, mu, x, 0);
 }
