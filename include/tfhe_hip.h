@@ -135,6 +135,9 @@ int tfhe_hip_load_keys_fft(tfhe_hip_ctx *ctx, const double *bkfft, const int32_t
  *   arithmetic mode needs and marks the keys present.  Within one process use a device group instead. */
 int tfhe_hip_keys_device_buffers(tfhe_hip_ctx *ctx, void *ptrs[3], size_t bytes[3]);
 int tfhe_hip_keys_adopt(tfhe_hip_ctx *ctx);
+/* 64-bit content fingerprints of the three key buffers (computed on the device; equal contents give equal values on
+ * every device and rank): what the ranks compare after the broadcast, before anyone adopts. */
+int tfhe_hip_keys_fingerprint(tfhe_hip_ctx *ctx, uint64_t out[3]);
 /* device copy of the FFT key back in the reference layout (parity check of the conversion) */
 int tfhe_hip_get_bkfft(tfhe_hip_ctx *ctx, double *bkfft_out);
 
@@ -265,6 +268,10 @@ tfhe_hip_ctx *tfhe_hip_group_ctx(tfhe_hip_group *group, int member);   /* borrow
 int tfhe_hip_group_load_keys_coef(tfhe_hip_group *group, const int32_t *bk_coef, const int32_t *ks);
 int tfhe_hip_group_load_keys_fft(tfhe_hip_group *group, const double *bkfft, const int32_t *ks);
 int tfhe_hip_group_set_arithmetic(tfhe_hip_group *group, int mode);
+/* how member `member` received its keys: 0 uploaded from the host (member 0), 1 device-to-device copy with peer access
+ * enabled (xGMI where the GPUs are linked), 2 peer copy staged by the runtime (no peer access offered), 3 copy within one
+ * device (the member shares member 0's GPU).  Replicas are verified against member 0's fingerprints before use. */
+int tfhe_hip_group_key_path(const tfhe_hip_group *group, int member);
 int tfhe_hip_group_gate_batch(tfhe_hip_group *group, int gate, int32_t *out, const int32_t *a, const int32_t *b,
                               const int32_t *c, int64_t count);
 

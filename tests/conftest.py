@@ -43,3 +43,15 @@ def engine(keys):
     e.load_keys_coef(keys.bk_coef, keys.ks)
     yield e
     e.close()
+
+
+@pytest.fixture(scope="session")
+def fast(keys):
+    """a second context on GPU 0 in the FAST arithmetic mode (tfhe_hip_set_arithmetic), the bench headline's mode"""
+    from tfhe_amd import Engine
+    e = Engine(0)
+    e.set_arithmetic("fast")          # before the keys: the FAST key is derived at load
+    e.load_keys_coef(keys.bk_coef, keys.ks)
+    assert e.arithmetic == "fast"
+    yield e
+    e.close()

@@ -171,3 +171,38 @@ def test_device_group_equals_single_context(engine, client, keys):
         assert np.array_equal(client.decrypt(keys, f)[0], 1 - (bits[0] & bits[1]))
     finally:
         g.close()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the command form the driver uses for N = 1): bench.py starts
+    torch.distributed.run as a child process before touching the GPU and relays rank 0's line.  Two ranks share the one
+    GPU of the test box, so the collectives run over gloo (RCCL needs one device per rank); the key broadcast goes through
+    the verified path (fingerprints compared across the ranks)."""
+    import json
+    env = dict(os.environ, TFHE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "1100", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["keys_via"] == "gloo-staged" and line["rccl_ranks"] == 0
+    assert line["config"]["outputs_decrypt_correctly"] and line["value"] > 0
+    assert line["kernel_ms"]["blind_rotate_per_rank_min"] <= line["kernel_ms"]["blind_rotate_per_rank_max"]
+    assert line["exact_arithmetic_same_run"]["value"] > 0
+
+
+def test_group_records_how_keys_travelled(engine, keys):
+    """tfhe_hip_group_key_path: member 0 uploaded from the host, members on the same device copied within it (3); on a
+    multi-GPU host 1 = peer access enabled (xGMI), 2 = staged.  Replicas are fingerprint-checked against member 0."""
+    from tfhe_amd import Group
+    g = Group([0, 0])
+    try:
+        g.load_keys_coef(keys.bk_coef, keys.ks)
+        assert g.key_paths() == [0, 3]
+    finally:
+        g.close()
+    fp = engine.key_fingerprints()
+    assert len(set(fp)) == 3 and all(0 < v < 1 << 64 for v in fp)
+    assert engine.key_fingerprints() == fp

@@ -34,17 +34,6 @@ def wrap(d):
     return (np.asarray(d, np.int64) + 2**31) % 2**32 - 2**31
 
 
-@pytest.fixture(scope="module")
-def fast(keys):
-    from tfhe_amd import Engine
-    e = Engine(0)
-    e.set_arithmetic("fast")          # before the keys: the FAST key is derived at load
-    e.load_keys_coef(keys.bk_coef, keys.ks)
-    assert e.arithmetic == "fast"
-    yield e
-    e.close()
-
-
 def test_forward_spectra_within_1e10(fast, oracle):
     rng = np.random.default_rng(10)
     ints = rng.integers(-64, 64, (16, P.N)).astype(np.int32)

@@ -1143,21 +1143,60 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
         for (int q = 0; q < 4; q++) dq[q * 64] = u32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
     };
     if (!fwd_role && nact > 0) prepare_column(__builtin_amdgcn_readfirstlane(act[0]) & 0xffff);
-    auto load_key_row = [&](c64 (&kb)[2][8], int it) {  // key row `wave` of TGSW sample `it` (Z_k order): 16 coalesced 1 KB loads
-        const c64 *row = A.bk + ((size_t) it * kKpl + wave) * 2 * kNh + lane;
+    // The 2l x 2 products of a CMux are accumulated exactly as the throughput kernel does it (cmux_fast: one FMA chain per
+    // spectrum value and column over the rows w = 0..2l-1 in order, starting from zero), so that a gate gives the same
+    // ciphertext whichever kernel its batch size selects.  The chains are spread over ALL waves: unit u = (slice q = u & 7
+    // of 64 spectrum values Z_(q<<6|lane), column u >> 3), wave handles the units wave, wave + W, ...: it reads the 2l
+    // spectra of its slice from the forward waves' buffers, multiplies with its own 2l key values per unit (requested one
+    // CMux ahead) and leaves the sum in the column's sum buffer.
+    constexpr int kW = kCoopFastWaves, kUnits = (16 + kW - 1) / kW;
+    c64 *sum0 = bufs + (size_t) 3 * kNh, *sum1 = bufs + (size_t) 5 * kNh;  // the B halves of forward waves 1 and 2 (unused otherwise)
+    static_assert(kKpl >= 3, "sum buffers live in the B halves of forward waves 1 and 2");
+    auto load_mac_keys = [&](c64 (&kb)[kUnits][kKpl], int it) {  // 1 KB coalesced loads, Z_k order
 #pragma unroll
-        for (int c2 = 0; c2 < 2; c2++)
+        for (int k = 0; k < kUnits; k++) {
+            const int u = wave + k * kW;
+            if (u < 16) {
+                const c64 *src = A.bk + ((size_t) it * kKpl * 2 + (u >> 3)) * kNh + ((u & 7) << 6) + lane;
 #pragma unroll
-            for (int r = 0; r < 8; r++) kb[c2][r] = row[c2 * kNh + r * 64];
+                for (int w = 0; w < kKpl; w++) kb[k][w] = src[(size_t) w * 2 * kNh];
+            }
+        }
     };
-    c64 kb[2][8];
+    auto mac_units = [&](const c64 (&kb)[kUnits][kKpl]) {
+        if (kW == 8) {  // both units of a wave share the slice: one read of the spectra
+            c64 a[kKpl];
+#pragma unroll
+            for (int w = 0; w < kKpl; w++) a[w] = bufs[(size_t) w * 2 * kNh + (wave << 6) + lane];
+            c64 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
+#pragma unroll
+            for (int w = 0; w < kKpl; w++) {
+                brf::cmac(s0, a[w], kb[0][w]);
+                brf::cmac(s1, a[w], kb[kUnits - 1][w]);
+            }
+            sum0[(wave << 6) + lane] = s0;
+            sum1[(wave << 6) + lane] = s1;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kUnits; k++) {
+                const int u = wave + k * kW;
+                if (u < 16) {
+                    c64 a[kKpl];
+#pragma unroll
+                    for (int w = 0; w < kKpl; w++) a[w] = bufs[(size_t) w * 2 * kNh + ((u & 7) << 6) + lane];
+                    c64 s = {0.0, 0.0};
+#pragma unroll
+                    for (int w = 0; w < kKpl; w++) brf::cmac(s, a[w], kb[k][w]);
+                    (u >> 3 ? sum1 : sum0)[((u & 7) << 6) + lane] = s;
+                }
+            }
+        }
+    };
+    c64 kb[kUnits][kKpl];
     TwPre<8> twa;  // levels 3..8 of the role's transform
-    if (fwd_role) {
-        if (nact > 0) load_key_row(kb, __builtin_amdgcn_readfirstlane(act[0]) >> 16);
-        tw_preload(twa, twl, brf::FS_FB);
-    } else {
-        tw_preload(twa, twl, brf::FS_IB);
-    }
+    if (nact > 0) load_mac_keys(kb, __builtin_amdgcn_readfirstlane(act[0]) >> 16);
+    if (fwd_role) tw_preload(twa, twl, brf::FS_FB);
+    else tw_preload(twa, twl, brf::FS_IB);
     __syncthreads();
 #if TFHE_HIP_COOP_TRACE
     long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp;
@@ -1166,7 +1205,7 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
 #define TR(k)
 #endif
     // one loop per role (the roles never change: what one role keeps in registers is dead in the other's loop); both run
-    // the same two barriers per CMux
+    // the same three barriers per CMux: spectra in LDS | sums in LDS | next differences in LDS
     if (fwd_role) {
 #pragma unroll 1
         for (int pos = 0; pos < nact; pos++) {
@@ -1198,15 +1237,14 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
             brf::fwd_phaseBC<brf::FS_FC>(v, TwView<8, brf::FS_FB>{twa});
             TR(1)
 #pragma unroll
-            for (int r = 0; r < 8; r++) {  // P_w = v * key row w
-                mineA[r * 64 + lane] = brf::cmul(v[r], kb[0][r]);
-                mineB[r * 64 + lane] = brf::cmul(v[r], kb[1][r]);
-            }
-            TR(2)
-            __syncthreads();  // all products in LDS; the forward waves are done with the differences
+            for (int r = 0; r < 8; r++) mineA[r * 64 + lane] = v[r];  // spectrum of row w: Z_(r<<6|lane)
+            __syncthreads();  // all spectra in LDS; the forward waves are done with the differences
             TR(3)
-            if (nxt) load_key_row(kb, nxt >> 16);  // arrives during the inverse transforms
-            __syncthreads();  // next differences in place; the inverse waves are done with the products
+            mac_units(kb);
+            TR(2)
+            __syncthreads();  // sums in place
+            if (nxt) load_mac_keys(kb, nxt >> 16);  // arrives during the inverse transforms
+            __syncthreads();  // next differences in place; the inverse waves are done with the scratch
             TR(3)
         }
     } else {
@@ -1218,30 +1256,20 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
             const int nxt = pos + 1 < nact ? __builtin_amdgcn_readfirstlane(act[pos + 1]) : 0;
             __syncthreads();
             TR(3)
+            mac_units(kb);
+            TR(2)
+            __syncthreads();
+            TR(3)
+            if (nxt) load_mac_keys(kb, nxt >> 16);
             c64 sp[8];
-            const c64 *src = bufs + ic * kNh + lane;
+            {
+                const c64 *src = (ic ? sum1 : sum0) + lane;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {  // the 2l products of four spectrum values at a time: 24 reads in flight
-                c64 u[4][kKpl];
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-#pragma unroll
-                    for (int w = 0; w < kKpl; w++)  // the inverse wants Y_(br3(r)<<6|lane) in register r
-                        u[q][w] = src[(size_t) w * 2 * kNh + (br3(h * 4 + q) << 6)];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    sp[h * 4 + q] = u[q][0];
-#pragma unroll
-                    for (int w = 1; w < kKpl; w++) {
-                        sp[h * 4 + q].re += u[q][w].re;
-                        sp[h * 4 + q].im += u[q][w].im;
-                    }
-                }
+                for (int r = 0; r < 8; r++) sp[r] = src[br3(r) << 6];  // the inverse wants Y_(br3(r)<<6|lane) in register r
             }
             TR(4)
-            // transpose scratch: a product buffer only this wave reads (column ic of forward wave 0)
+            // transpose scratch: a buffer nobody else touches until the next barrier (column ic of forward wave 0)
             c64 *iscr = ic ? mineB : mineA;
-            wave_sync();
             brf::inv_phaseA(sp, twu);
             t_write_A(iscr, sp, lane);
             wave_sync();
@@ -1904,6 +1932,21 @@ __global__ __launch_bounds__(256) void k_poly_mul2048_fast(const int32_t *__rest
 // bootstrapping key of the FAST mode from the exact mode's (physical slot x holds reference bin igray(x)): the same
 // doubles, re-indexed to Z_k order [poly][k] and conjugated where the fold asks for it - no arithmetic, so the key is
 // the reference's bkFFT bit for bit in both modes
+// 64-bit content fingerprint of a device buffer (tfhe_hip_keys_fingerprint): sum over the 8-byte words of mix(word, index).
+// The sum is commutative, so the atomic order does not matter: equal contents give equal fingerprints on every device.
+__global__ __launch_bounds__(256) void k_fingerprint(const unsigned long long *__restrict__ p, long long words,
+                                                     unsigned long long *__restrict__ out) {
+    unsigned long long h = 0;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (long long) gridDim.x * blockDim.x) {
+        unsigned long long z = p[i] + 0x9e3779b97f4a7c15ULL * (unsigned long long) (i + 1);  // splitmix64 finaliser
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        h += z ^ (z >> 31);
+    }
+    for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+
 __global__ void k_bk_to_fast(c64 *__restrict__ dst, const c64 *__restrict__ src, long long total) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -2301,7 +2344,7 @@ struct tfhe_hip_ctx {
     int8_t *kl = nullptr;    // [N][4][640][t][4] byte limbs (MFMA keyswitch)
     int ks_mfma = 1;
     bool have_keys = false;
-    DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc, abart, ks_part, jobs_br, jobs_ks, jobs_lin;
+    DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc, abart, ks_part, jobs_br, jobs_ks, jobs_lin, fp;
     std::vector<BrJob> h_br;
     std::vector<KsJob> h_ks;
     std::vector<int32_t> h_lin;
@@ -2310,6 +2353,8 @@ struct tfhe_hip_ctx {
     bool ev_br = false, ev_ks = false;
     bool in_mul2048 = false;  // the N = 2048 product is running its four N = 1024 products
     long long fault_chunk = -1;  // test hook: fail the host pipeline at this chunk once (TFHE_HIP_TEST_FAIL_CHUNK)
+    uint64_t key_print[3] = {0, 0, 0};  // group member 0: fingerprints of its key buffers, taken before replication
+    int key_path = 0;  // how the keys got here: 0 = uploaded / adopted, 1 = peer copy with peer access, 2 = peer copy staged by the runtime, 3 = same device
     int br_waves = 0;  // 0 = by batch size; TFHE_HIP_BR_WAVES=1|4|8 forces a shape, 6 the one-workgroup-per-ciphertext kernel
 };
 
@@ -2320,6 +2365,18 @@ constexpr size_t kKsDevBytes = (size_t) kN * kKsT * 3 * kKsRow * sizeof(int32_t)
 constexpr size_t kKsHostElems = (size_t) kN * kKsT * 4 * kCt;
 constexpr int kFftLds = kTwLaneEntries * (int) sizeof(c64) + 4 * kNh * (int) sizeof(c64);
 constexpr long long kPolyMulMaxBlocks = 256 * 2 * 4;  // product kernels: workgroups walk over the batch (two resident per CU, four rounds)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): set once, not per launch
+int set_max_lds_once(const void *kernel, int lds, int device) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &d : done)
+        if (d.first == kernel && d.second == device) return TFHE_HIP_OK;
+    HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    done.emplace_back(kernel, device);
+    return TFHE_HIP_OK;
+}
 
 template <int MODE>
 int launch_br(tfhe_hip_ctx *c, const BrArgs &A0, const c64 *custom_bk = nullptr) {
@@ -2389,16 +2446,17 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0, const c64 *custom_bk = nullptr)
     if (waves == kShapeCoop && MODE != MODE_EXTMUL && c->arith == TFHE_HIP_ARITH_FAST) {  // latency shape, FAST arithmetic
         A.tw = c->twf;
         A.bk = custom_bk ? custom_bk : c->bkf;
-        HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate_coop_fast<MODE == MODE_EXTMUL ? MODE_RAW : MODE>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kCoopFastLds));
+        if (int r = set_max_lds_once((const void *) k_blind_rotate_coop_fast<MODE == MODE_EXTMUL ? MODE_RAW : MODE>, kCoopFastLds,
+                                     c->device))
+            return r;
         hipLaunchKernelGGL((k_blind_rotate_coop_fast<MODE == MODE_EXTMUL ? MODE_RAW : MODE>), dim3((unsigned) A.B),
                            dim3(64 * kCoopFastWaves), kCoopFastLds, c->stream, A);
         HIPCHK(hipGetLastError());
         return TFHE_HIP_OK;
     }
     if (waves == kShapeCoop && MODE != MODE_EXTMUL) {  // one workgroup per ciphertext (latency shape)
-        HIPCHK(hipFuncSetAttribute((const void *) k_blind_rotate_coop<MODE == MODE_EXTMUL ? MODE_RAW : MODE>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kCoopLds));
+        if (int r = set_max_lds_once((const void *) k_blind_rotate_coop<MODE == MODE_EXTMUL ? MODE_RAW : MODE>, kCoopLds, c->device))
+            return r;
         hipLaunchKernelGGL((k_blind_rotate_coop<MODE == MODE_EXTMUL ? MODE_RAW : MODE>), dim3((unsigned) A.B),
                            dim3(64 * kCoopWaves), kCoopLds, c->stream, A);
         HIPCHK(hipGetLastError());
@@ -2414,7 +2472,7 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0, const c64 *custom_bk = nullptr)
     const size_t lds = (fast ? brf::kFastLaneEntries : kTwLaneEntries) * sizeof(c64) + (size_t) waves * kBrLdsPerWave;
     const unsigned grid = (unsigned) ((A.B + waves - 1) / waves);
     auto go = [&](auto kernel) -> int {
-        HIPCHK(hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        if (int r = set_max_lds_once((const void *) kernel, (int) lds, c->device)) return r;
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * waves), lds, c->stream, A);
         return TFHE_HIP_OK;
     };
@@ -2698,6 +2756,22 @@ int tfhe_hip_keys_adopt(tfhe_hip_ctx *c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (int r = build_fast_key(c)) return r;
     c->have_keys = true;
+    return TFHE_HIP_OK;
+}
+int tfhe_hip_keys_fingerprint(tfhe_hip_ctx *c, uint64_t out[3]) {
+    if (int r = check_ctx(c, false)) return r;
+    if (!out) return fail(TFHE_HIP_ERR_ARG, "null output array");
+    if (!c->bk || !c->ks || !c->kl) return fail(TFHE_HIP_ERR_NOKEY, "no key buffers");
+    const void *ptrs[3] = {c->bk, c->ks, c->kl};
+    const size_t bytes[3] = {kBkBytes, kKsDevBytes, (size_t) kN * 4 * kKsQ * 32};
+    HIPCHK(c->fp.reserve(3 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(c->fp.p, 0, 3 * sizeof(unsigned long long), c->stream));
+    for (int k = 0; k < 3; k++)
+        hipLaunchKernelGGL(k_fingerprint, dim3(2048), dim3(256), 0, c->stream, (const unsigned long long *) ptrs[k],
+                           (long long) (bytes[k] / 8), (unsigned long long *) c->fp.p + k);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->fp.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return TFHE_HIP_OK;
 }
 
@@ -3766,10 +3840,24 @@ void shard(long long count, int i, int n, long long &lo, long long &hi) {  // co
     lo = i * base + std::min<long long>(i, rem);
     hi = lo + base + (i < rem ? 1 : 0);
 }
-// device-to-device replica of member 0's keys (after tfhe_hip_load_keys_* on member 0)
-int replicate_keys(tfhe_hip_ctx *dst, const tfhe_hip_ctx *src) {
+// device-to-device replica of member 0's keys (after tfhe_hip_load_keys_* on member 0).  Between two devices the copy
+// goes over xGMI only with peer access enabled: asked for and switched on here when the runtime offers it (once per
+// pair; "already enabled" is fine); otherwise hipMemcpyPeerAsync is staged through the host by the runtime.  Which of the
+// two happened is kept per member (tfhe_hip_group_key_path), and the replica is checked against the source's fingerprints.
+int replicate_keys(tfhe_hip_ctx *dst, tfhe_hip_ctx *src) {
     HIPCHK(hipSetDevice(dst->device));
     dst->have_keys = false;
+    dst->key_path = 3;
+    if (dst->device != src->device) {
+        int can = 0;
+        HIPCHK(hipDeviceCanAccessPeer(&can, dst->device, src->device));
+        dst->key_path = 2;
+        if (can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) dst->key_path = 1;
+            (void) hipGetLastError();  // "already enabled" is not an error of this call
+        }
+    }
     if (!dst->bk) HIPCHK(hipMalloc((void **) &dst->bk, kBkBytes));
     if (!dst->ks) HIPCHK(hipMalloc((void **) &dst->ks, kKsDevBytes));
     const size_t kl_bytes = (size_t) kN * 4 * kKsQ * 32;
@@ -3778,6 +3866,11 @@ int replicate_keys(tfhe_hip_ctx *dst, const tfhe_hip_ctx *src) {
     HIPCHK(hipMemcpyPeerAsync(dst->ks, dst->device, src->ks, src->device, kKsDevBytes, dst->stream));
     HIPCHK(hipMemcpyPeerAsync(dst->kl, dst->device, src->kl, src->device, kl_bytes, dst->stream));
     HIPCHK(hipStreamSynchronize(dst->stream));
+    uint64_t got[3];
+    if (int r = tfhe_hip_keys_fingerprint(dst, got)) return r;
+    if (got[0] != src->key_print[0] || got[1] != src->key_print[1] || got[2] != src->key_print[2])
+        return fail(TFHE_HIP_ERR_HIP, "replicated keys differ from the source's (device " + std::to_string(src->device) + " -> " +
+                                          std::to_string(dst->device) + ")");
     if (int r = build_fast_key(dst)) return r;
     dst->have_keys = true;
     return TFHE_HIP_OK;
@@ -3819,7 +3912,13 @@ tfhe_hip_ctx *tfhe_hip_group_ctx(tfhe_hip_group *g, int i) {
     return g && i >= 0 && i < (int) g->ctx.size() ? g->ctx[i] : nullptr;
 }
 static int group_replicate(tfhe_hip_group *g) {
+    if (g->ctx.size() > 1)
+        if (int r = tfhe_hip_keys_fingerprint(g->ctx[0], g->ctx[0]->key_print)) return r;
     return group_run(g, [g](int i) { return i == 0 ? TFHE_HIP_OK : replicate_keys(g->ctx[i], g->ctx[0]); });
+}
+int tfhe_hip_group_key_path(const tfhe_hip_group *g, int member) {
+    if (!g || member < 0 || member >= (int) g->ctx.size()) return TFHE_HIP_ERR_ARG;
+    return g->ctx[member]->key_path;
 }
 int tfhe_hip_group_load_keys_coef(tfhe_hip_group *g, const int32_t *bk_coef, const int32_t *ks) {
     if (!g) return fail(TFHE_HIP_ERR_ARG, "null group");

@@ -69,7 +69,7 @@ EXPORTS = [
     "tfhe_hip_set_arithmetic", "tfhe_hip_get_arithmetic",
     "tfhe_hip_group_create", "tfhe_hip_group_destroy", "tfhe_hip_group_size", "tfhe_hip_group_ctx",
     "tfhe_hip_group_load_keys_coef", "tfhe_hip_group_load_keys_fft", "tfhe_hip_group_set_arithmetic",
-    "tfhe_hip_group_gate_batch",
+    "tfhe_hip_group_gate_batch", "tfhe_hip_group_key_path", "tfhe_hip_keys_fingerprint",
     "tfhe_hip_tgsw_fft_extern_mul_batch", "tfhe_hip_tgsw_extern_mul_batch", "tfhe_hip_tlwe_addmul_r_batch",
 ]
 
@@ -184,6 +184,10 @@ class Group:
         code = {"exact": 0, "fast": 1}[mode] if isinstance(mode, str) else int(mode)
         self._chk(self.lib.tfhe_hip_group_set_arithmetic(self.handle, code), "group_set_arithmetic")
 
+    def key_paths(self):
+        """per member: 0 host upload, 1 peer copy with peer access, 2 peer copy staged by the runtime, 3 same device"""
+        return [self.lib.tfhe_hip_group_key_path(self.handle, i) for i in range(len(self))]
+
     def gate_batch(self, gate, a=None, b=None, c=None, count=None):
         P = self.params
         a, b, c = (_i32(x, (P.n + 1,)) for x in (a, b, c))
@@ -274,6 +278,12 @@ class Engine:
 
     def adopt_keys(self):
         self._chk(self.lib.tfhe_hip_keys_adopt(self.ctx), "keys_adopt")
+
+    def key_fingerprints(self):
+        """64-bit content fingerprints of the three key buffers, computed on the device"""
+        out = (ctypes.c_uint64 * 3)()
+        self._chk(self.lib.tfhe_hip_keys_fingerprint(self.ctx, out), "keys_fingerprint")
+        return [int(v) for v in out]
 
     def get_bkfft(self):
         P = self.params

@@ -76,29 +76,55 @@ def broadcast_secret(keys, src=0, params=None, device=None):
     return KeySet(int(h[0]), h[1:1 + P.n].astype(np.int32), h[1 + P.n:].astype(np.int32), None, None)
 
 
-def broadcast_keys_device(engine, src=0):
+def broadcast_keys_device(engine, src=0, verify=False, device=None):
     """replicates the cloud keys of rank `src`'s engine (already loaded there) into every other rank's engine: one RCCL
     broadcast per device-resident key buffer, no host copy and no second conversion (tfhe_hip_keys_device_buffers /
     tfhe_hip_keys_adopt).  With a backend that takes no device tensors (gloo, the one-GPU rehearsal) the same buffers
-    are staged through the host."""
+    are staged through the host.
+    verify=True: every rank fingerprints its three buffers on its GPU (tfhe_hip_keys_fingerprint) and the ranks compare
+    before anyone adopts; an exception on any rank or a mismatch makes ALL ranks return "host" without adopting (the
+    caller then distributes the keys through host memory: broadcast_keys + load_keys_coef).  Returns "rccl" when the
+    buffers travelled as device tensors, "gloo-staged" when through host tensors, "host" on failure, None if not
+    distributed."""
     import torch
     dist = _dist()
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return
-    engine.sync()                                    # the engine's stream is not torch's
+        return None
     on_device = dist.get_backend() == "nccl"
-    for ptr, nbytes in engine.key_buffers():
-        t = torch.as_tensor(_DevBytes(ptr, nbytes), device=torch.device("cuda", torch.cuda.current_device()))
-        if on_device:
-            dist.broadcast(t, src=src)
-        else:
-            h = t.cpu()
-            dist.broadcast(h, src=src)
-            if dist.get_rank() != src:
-                t.copy_(h)
-    torch.cuda.synchronize()
+    cdev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if on_device
+                                              else torch.device("cpu"))
+    ok, err = 1, None
+    try:
+        engine.sync()                                    # the engine's stream is not torch's
+        for ptr, nbytes in engine.key_buffers():
+            t = torch.as_tensor(_DevBytes(ptr, nbytes), device=torch.device("cuda", torch.cuda.current_device()))
+            if on_device:
+                dist.broadcast(t, src=src)
+            else:
+                h = t.cpu()
+                dist.broadcast(h, src=src)
+                if dist.get_rank() != src:
+                    t.copy_(h)
+        torch.cuda.synchronize()
+    except Exception as e:                               # noqa: BLE001 - any failure here means "use the host path"
+        if not verify:
+            raise
+        ok, err = 0, e
+    if verify:
+        prints = engine.key_fingerprints() if ok else [0, 0, 0]
+        mine = torch.tensor([ok] + [p - (1 << 64) if p >= (1 << 63) else p for p in prints], dtype=torch.int64, device=cdev)
+        parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine)
+        rows = [p.cpu().tolist() for p in parts]
+        if any(r[0] != 1 for r in rows) or any(r[1:] != rows[src][1:] for r in rows):
+            if dist.get_rank() == src:
+                import sys
+                print("[broadcast_keys_device] device-side key broadcast failed (%r; fingerprints %r): falling back to "
+                      "the host path" % (err, rows), file=sys.stderr, flush=True)
+            return "host"
     if dist.get_rank() != src:
         engine.adopt_keys()
+    return "rccl" if on_device else "gloo-staged"
 
 
 def all_gather_rows(local, count, device=None):
