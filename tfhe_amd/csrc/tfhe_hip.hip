@@ -1022,18 +1022,23 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// latency shape in the FAST arithmetic mode: the same division of one ciphertext over one workgroup of 2l waves, with the
-// folded transforms of fast_core.h.  Per CMux, two workgroup barriers:
-//   every wave w:   digits of decomposition row w (from the prepared differences), forward transform, product with key
-//                   row w (both columns) into its LDS buffers                                            -> barrier
-//   waves 0 and 1:  sum of the 2l products of column 0 / 1, inverse transform (512 points, one wave: the folded inverse
-//                   is a quarter of the exact mode's work and is not split further), accumulator update, and - the
-//                   column being theirs alone - its rotated, prepared differences for the next CMux      -> barrier
-//   every wave:     key row w of the next CMux requested right after the first barrier (arrives during the inverse)
+// latency shape in the FAST arithmetic mode: one ciphertext per workgroup of 2l forward waves + one inverse wave per
+// accumulator column, with the folded transforms of fast_core.h.  Per CMux, three workgroup barriers:
+//   forward wave w: digits of decomposition row w (from the prepared differences), forward transform, spectrum into its
+//                   LDS buffer                                                                           -> barrier
+//   every wave:     its share of the 2 x 512 FMA chains over the 2l rows (spectra from LDS x key values requested one CMux
+//                   ahead), in the throughput kernel's order: a gate's ciphertext does not depend on which kernel its
+//                   batch size selects; sums into the column's sum buffer                                -> barrier
+//   inverse waves:  inverse transform of their column's sums (512 points, one wave), accumulator update, and - the column
+//                   being theirs alone - its rotated, prepared differences for the next CMux (measured: the forward waves
+//                   gathering them for themselves moves the same 1.1 k ticks onto the six forward waves, two of which
+//                   share a SIMD: 2.22 against 2.05 ms per gate)                                         -> barrier
+// Key values of the next CMux: forward waves request theirs after the second barrier, inverse waves at the end of theirs.
 // Rotations by 0 are skipped through a list of the non-zero rotation amounts built once per launch.  The twiddles of
 // both directions stay in registers (one ciphertext per CU: registers are not the constraint here).
-// LDS: twiddle image 24 KB | accumulator mirror 8 KB | per wave: products of column 0 (also the wave's transpose
-//      scratch) and column 1, 8 KB each | rotation list | prepared differences 8 KB
+// LDS: twiddle image 24 KB | accumulator mirror 8 KB | per forward wave: A (transpose scratch, then its spectrum) and B
+//      (B of waves 1 and 2: the sums of column 0 / 1; A and B of wave 0: the inverse waves' scratch), 8 KB each
+//      | rotation list | prepared differences 8 KB
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kCoopFastWaves = kKpl + 2;  // 2l forward waves, one inverse wave per accumulator column
 constexpr int kCoopFastLds = brf::kFastLaneEntries * (int) sizeof(c64) + 2 * kN * 4 + kKpl * 2 * kNh * (int) sizeof(c64) +
@@ -1260,7 +1265,6 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
             TR(2)
             __syncthreads();
             TR(3)
-            if (nxt) load_mac_keys(kb, nxt >> 16);
             c64 sp[8];
             {
                 const c64 *src = (ic ? sum1 : sum0) + lane;
@@ -1297,6 +1301,10 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
             if (nxt) {
                 wave_sync();
                 prepare_column(nxt & 0xffff);
+                // this wave's key values of the next CMux: requested only now, when the forward waves' requests (issued
+                // after the second barrier, 72 KB through the CU's one vector-memory pipe) have drained - issued next to
+                // them they queue behind them and hold up the inverse transform, which is the critical path
+                load_mac_keys(kb, nxt >> 16);
             }
             TR(6)
             __syncthreads();
