@@ -292,8 +292,12 @@ void tfhe_hip_param_set(int32_t out[8]);
  * LWE key (host int32[n], key bits 0/1), and lwePhase (lwe-functions.cpp:63-72; bootsSymDecrypt = phase > 0).
  * The reference's generator (std::default_random_engine + normal_distribution) is not portable, so these reproduce
  * the portable generator of tfhe_amd/csrc/client_keys.c bit for bit: sample i of a call is a function of
- * (seed, first_index + i, bit, key) - equal to tfhe_client_encrypt for first_index = 0.  Parity with the reference
- * itself is therefore semantic only (its own lwePhase decrypts these samples; tests/test_gpu_parity.py). */
+ * (seed, first_index + i, bit, key) - equal to tfhe_client_encrypt for first_index = 0.  The DISTRIBUTIONS are the
+ * reference's: uniform masks and key bits, and noise of its law - gaussian32 (numeric-functions.cpp:22-34): a centred
+ * Gaussian of the parameter set's standard deviation truncated toward zero to a Torus32 - drawn by integer table
+ * inversion (tfhe_amd/csrc/gauss_cdt.h: 1,024 steps per sigma, tail to 9.16 sigma) and checked against the reference's
+ * own gaussian32 (tests/test_oracle_vs_ref.py, tests/test_client.py).  Parity with the reference's streams is
+ * semantic (its own lwePhase decrypts these samples; tests/test_gpu_parity.py). */
 int tfhe_hip_encrypt_batch(tfhe_hip_ctx *ctx, int32_t *out, uint64_t seed, int64_t first_index, const int32_t *lwe_key,
                            const uint8_t *bits, int64_t count);
 /* the same with the ciphertexts written to device memory (e.g. rows of a netlist pool); lwe_key and bits stay host */

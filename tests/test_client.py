@@ -55,3 +55,29 @@ def test_bootstrapping_key_rows_are_tgsw_of_key_bits(keys, oracle):
                 msg = (-(s2.astype(np.int64)) * int(keys.lwe_key[i]) * h) % 2**32
             diff = (phase - msg + 2**31) % 2**32 - 2**31
             assert np.abs(diff).max() < 2**32 * 2**-25 * 8
+
+
+def test_noise_law_is_the_references_gaussian(client):
+    """gaussian32 (src/libtfhe/numeric-functions.cpp:22-34): normal_distribution(0, sigma), truncated toward zero to a
+    Torus32.  The client samples it by integer table inversion (gauss_cdt.h): standard deviation, symmetry, shape
+    (kurtosis 3, mass beyond 1 / 2 / 3 sigma) on four million samples; the tail beyond 6 sigma through the inversion itself"""
+    from math import erfc, sqrt
+    for m, sigma in ((1 << 25, 2.0 ** 17), (1 << 15, 128.0)):          # 2^-15 (LWE, keyswitch) and 2^-25 (bootstrapping key)
+        x = client.noise(11, m, 4_000_000).astype(np.float64)
+        # truncation toward zero shrinks |x| by 1/2 LSB on average: variance sigma^2 - sigma sqrt(2/pi) + 1/3
+        want_std = sqrt(sigma * sigma - sigma * sqrt(2 / np.pi) + 1 / 3)
+        assert abs(x.std() / want_std - 1) < 2e-3
+        assert abs(x.mean()) < 4 * sigma / sqrt(x.size)
+        z = x / sigma
+        assert abs((z ** 4).mean() / (z ** 2).mean() ** 2 - 3) < 0.02
+        for k in (1, 2, 3, 4):
+            p = erfc((np.floor(k * sigma) + 1) / sigma / sqrt(2))     # |trunc(y)| > k sigma  <=>  |y| >= floor(k sigma) + 1
+            assert abs((np.abs(x) > k * sigma).mean() - p) < 5 * sqrt(p / x.size) + 2e-5, k
+        assert (x > 0).mean() - (x < 0).mean() < 2e-3
+    # the tail: uniform words just below 2^64 P(|z| < 6) / at the top of the range land at 6 / beyond 9 sigma
+    m, sigma = 1 << 25, 2.0 ** 17
+    w6 = int((1 - erfc(6 / sqrt(2))) * 2.0 ** 64)
+    assert 5.99 < client.noise_from_words(w6, 0, m) / sigma < 6.01
+    assert -6.01 < client.noise_from_words(w6, 1 << 63, m) / sigma < -5.99
+    assert 9.1 < client.noise_from_words(2 ** 64 - 1, 0, m) / sigma < 9.2            # where the 64-bit table runs out
+    assert client.noise_from_words(0, 0, m) == 0 and abs(client.noise_from_words(0, (1 << 63) - 1, m)) < sigma / 1024 + 1

@@ -81,3 +81,19 @@ def test_gates_with_reference_generated_keys(oracle, ref):
         ref.ref_gate(gate, P(want), P(cts[0]), P(cts[1]), P(cts[2]))
         assert np.array_equal(oracle.gate(ok, gate, cts[0], cts[1], cts[2]), want), gate
     oracle.lib.oracle_keys_free(ok)
+
+
+def test_client_noise_follows_the_references_gaussian32(ref, client):
+    """the reference's own gaussian32 (numeric-functions.cpp:22-27), 300,000 draws at each of the two standard deviations,
+    against the client's integer sampler: two-sample Kolmogorov-Smirnov, equal standard deviations"""
+    from scipy.stats import ks_2samp
+    ref.gaussian32.restype = ctypes.c_int32
+    ref.gaussian32.argtypes = [ctypes.c_int32, ctypes.c_double]
+    seed = (ctypes.c_uint32 * 1)(99)
+    ref.tfhe_random_generator_setSeed(seed, 1)
+    for m, sigma in ((1 << 25, 2.0 ** -15), (1 << 15, 2.0 ** -25)):
+        r = np.array([ref.gaussian32(0, sigma) for _ in range(300_000)], np.float64)
+        c = client.noise(12, m, 300_000).astype(np.float64)
+        assert abs(r.std() / c.std() - 1) < 0.01
+        assert ks_2samp(r, c).pvalue > 1e-3
+        assert np.abs(r).max() < 6.5 * sigma * 2 ** 32 and np.abs(c).max() < 6.5 * sigma * 2 ** 32

@@ -32,6 +32,19 @@ class Client:
         if not os.path.exists(path):
             raise RuntimeError("%s not built: run `python -m tfhe_amd.build`" % path)
         self.lib = ctypes.CDLL(path)
+        if self.lib.tfhe_client_selftest() != 1:
+            raise RuntimeError("noise table self check failed: this host's libm rounds erfcl differently (keys would differ)")
+
+    def noise(self, seed, sigma_times_2_40, count):
+        """`count` centred noise samples (Torus32) of standard deviation sigma_times_2_40 / 2^40: the law of every noise term
+        this client draws (gauss_cdt.h), exposed so that tests can check it against the reference's gaussian32"""
+        out = np.zeros(count, np.int32)
+        self.lib.tfhe_client_noise(ctypes.c_uint64(seed), ctypes.c_int64(sigma_times_2_40), ctypes.c_int64(count), _p(out))
+        return out
+
+    def noise_from_words(self, w_mag, w_pos, sigma_times_2_40):
+        self.lib.tfhe_client_noise_from_words.restype = ctypes.c_int32
+        return self.lib.tfhe_client_noise_from_words(ctypes.c_uint64(w_mag), ctypes.c_uint64(w_pos), ctypes.c_int64(sigma_times_2_40))
 
     def keygen(self, seed=42):
         P = self.params

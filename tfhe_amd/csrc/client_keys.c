@@ -16,14 +16,16 @@
  * generator (the reference draws from std::default_random_engine + std::normal_distribution, whose streams are
  * not reproducible across standard libraries), so that tests, smoke() and bench.py regenerate identical keys on
  * the GPU box from a seed instead of shipping 145 MB of key files.  Distributions: key bits and masks uniform;
- * noise = Irwin-Hall(12) approximation of a centred Gaussian with the reference's standard deviations
- * (2^-15 for LWE_n / keyswitch rows, 2^-25 for the bootstrapping key; tfhe_gate_bootstrapping.cpp:62-63; for the
- * 80-bit set 2.44e-5 and 7.18e-9, :35-36).
+ * noise = the reference's law, a centred Gaussian truncated toward zero to a Torus32 (gaussian32,
+ * numeric-functions.cpp:22-34), sampled by integer table inversion (gauss_cdt.h; tail to 9.16 sigma) with the
+ * reference's standard deviations (2^-15 for LWE_n / keyswitch rows, 2^-25 for the bootstrapping key;
+ * tfhe_gate_bootstrapping.cpp:62-63; for the 80-bit set 2.44e-5 and 7.18e-9, :35-36).
  */
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include "gauss_cdt.h"
 
 /* one library per parameter set, as for libtfhe_hip (include/tfhe_hip.h): -DTFHE_HIP_LAMBDA=80 selects the 80-bit set.
  * Noise multipliers: standard deviation x 2^40, rounded (tfhe_gate_bootstrapping.cpp:35-36,62-63). */
@@ -62,17 +64,31 @@ static uint64_t rng_next(rng_t *r) { /* xoshiro256** */
     return res;
 }
 static inline int32_t rng_torus(rng_t *r) { return (int32_t) (uint32_t) (rng_next(r) >> 32); }
-/* centred noise with standard deviation m / 2^40 (as a Torus32; m = 2^25 gives 2^-15 and rounds exactly as the
- * shift by 15 it replaces): the sum of 12 uniform 32-bit words has
- * variance 2^64, i.e. standard deviation exactly 2^32 = "1.0" on the torus scale */
+/* centred Gaussian noise with standard deviation m / 2^40 on the torus (m = 2^25 gives 2^-15): two words of the stream */
+static uint64_t g_cdt[GAUSS_CDT_BINS];
+static int g_cdt_ok = 0;
+static pthread_once_t g_cdt_once = PTHREAD_ONCE_INIT;
+static void cdt_init(void) { g_cdt_ok = gauss_cdt_build(g_cdt, NULL); }
+/* 1 if the noise table has the pinned fingerprint on this host (a libm that rounds differently changes keys) */
+int tfhe_client_selftest(void) {
+    pthread_once(&g_cdt_once, cdt_init);
+    return g_cdt_ok;
+}
 static int32_t rng_gauss(rng_t *r, int64_t m) {
-    int64_t s = 0;
-    for (int i = 0; i < 6; i++) {
-        uint64_t w = rng_next(r);
-        s += (int64_t) (w >> 32) + (int64_t) (w & 0xffffffffu);
-    }
-    s -= (int64_t) 6 << 32;
-    return (int32_t) ((s * m + ((int64_t) 1 << 39)) >> 40); /* |s| < 2^35, m < 2^26 */
+    const uint64_t w_mag = rng_next(r), w_pos = rng_next(r);
+    return gauss_cdt_value(g_cdt, w_mag, w_pos, m);
+}
+/* one centred noise sample of standard deviation m / 2^40 from stream `stream` of `seed`, draw `index` of it (tests: the
+ * law itself - sigma, symmetry, tail - is checked on a few million of these) */
+int32_t tfhe_client_noise_from_words(uint64_t w_mag, uint64_t w_pos, int64_t m) { /* the inversion itself (tests: tail) */
+    pthread_once(&g_cdt_once, cdt_init);
+    return gauss_cdt_value(g_cdt, w_mag, w_pos, m);
+}
+void tfhe_client_noise(uint64_t seed, int64_t m, int64_t count, int32_t *out) {
+    rng_t r;
+    pthread_once(&g_cdt_once, cdt_init);
+    rng_seed(&r, seed, 7);
+    for (int64_t i = 0; i < count; i++) out[i] = rng_gauss(&r, m);
 }
 
 /* b += key * a  in Z[X]/(X^N+1), key binary (reference torusPolynomialAddMulR, used at tlwe-functions.cpp:35) */
@@ -113,6 +129,7 @@ static void *bk_worker(void *arg) {
 void tfhe_client_keygen(uint64_t seed, int32_t *lwe_key /*n*/, int32_t *tlwe_key /*N*/,
                         int32_t *bk_coef /*[n][kpl][2][N]*/, int32_t *ks /*[N][t][base][n+1]*/) {
     rng_t r;
+    pthread_once(&g_cdt_once, cdt_init);
     rng_seed(&r, seed, 1);
     for (int i = 0; i < CN; i++) lwe_key[i] = (int32_t) (rng_next(&r) >> 63);
     rng_seed(&r, seed, 2);
@@ -149,6 +166,7 @@ void tfhe_client_keygen(uint64_t seed, int32_t *lwe_key /*n*/, int32_t *tlwe_key
 /* bootsSymEncrypt: mu = +-1/8, noise 2^-15 */
 void tfhe_client_encrypt(uint64_t seed, const int32_t *lwe_key, const uint8_t *bits, int64_t count,
                          int32_t *out /*[count][n+1]*/) {
+    pthread_once(&g_cdt_once, cdt_init);
     for (int64_t c = 0; c < count; c++) {
         rng_t r;
         rng_seed(&r, seed, 0x100000000ULL + (uint64_t) c);

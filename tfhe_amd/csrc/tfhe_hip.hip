@@ -27,6 +27,7 @@
 #include <vector>
 #include "br_core.h"
 #include "fast_core.h"
+#include "gauss_cdt.h"
 #include "internal.h"
 #include "../../include/tfhe_hip.h"
 
@@ -2062,7 +2063,8 @@ __global__ __launch_bounds__(256) void k_rows_sum(int32_t *__restrict__ out, con
 // (tfhe_gate_bootstrapping.cpp:154-159 = lweSymEncrypt, lwe-functions.cpp:44-56) and lwePhase (:63-72).
 // The reference draws from std::default_random_engine + normal_distribution, whose streams are not portable; these
 // kernels reproduce, bit for bit, the portable generator of tfhe_amd/csrc/client_keys.c (one xoshiro256** stream per
-// sample, Irwin-Hall(12) noise of standard deviation 2^-15), so a ciphertext is a function of (seed, index, bit, key).
+// sample; noise = the reference's law, gaussian32 of numeric-functions.cpp:22-34, by the integer table inversion of
+// gauss_cdt.h, standard deviation 2^-15), so a ciphertext is a function of (seed, index, bit, key).
 // ---------------------------------------------------------------------------------------------------------------
 #if TFHE_HIP_LAMBDA == 128
 constexpr int64_t kKsNoiseM = (int64_t) 1 << 25, kBkNoiseM = (int64_t) 1 << 15;  // 2^-15, 2^-25 (x 2^40)
@@ -2088,28 +2090,23 @@ __device__ __forceinline__ uint64_t crng_next(ClientRng &r) {  // xoshiro256**
     r.s[2] ^= r.s[0]; r.s[3] ^= r.s[1]; r.s[1] ^= r.s[2]; r.s[0] ^= r.s[3]; r.s[2] ^= t; r.s[3] = crng_rotl(r.s[3], 45);
     return res;
 }
-__device__ __forceinline__ int32_t crng_gauss(ClientRng &r, int64_t m) {  // standard deviation m / 2^40
-
-    int64_t s = 0;
-    for (int i = 0; i < 6; i++) {
-        const uint64_t w = crng_next(r);
-        s += (int64_t) (w >> 32) + (int64_t) (w & 0xffffffffu);
-    }
-    s -= (int64_t) 6 << 32;
-    return (int32_t) ((s * m + ((int64_t) 1 << 39)) >> 40);
+// gaussian32 (numeric-functions.cpp:22-34) by integer table inversion, as rng_gauss of client_keys.c: two words of the stream
+__device__ __forceinline__ int32_t crng_gauss(ClientRng &r, int64_t m, const uint64_t *__restrict__ cdt) {
+    const uint64_t w_mag = crng_next(r), w_pos = crng_next(r);
+    return gauss_cdt_value(cdt, w_mag, w_pos, m);
 }
 // one thread per sample (the generator of a sample is sequential); the 630 mask words of 64 samples pass through LDS
 // so that the global stores are coalesced rows
 __global__ __launch_bounds__(64) void k_client_encrypt(uint64_t seed, const int32_t *__restrict__ key,
                                                        const uint8_t *__restrict__ bits, long long first, long long count,
-                                                       int32_t *__restrict__ out) {
+                                                       int32_t *__restrict__ out, const uint64_t *__restrict__ cdt) {
     __shared__ int32_t tile[64][65];
     const long long c0 = (long long) blockIdx.x * 64, c = c0 + threadIdx.x;
     ClientRng r;
     crng_seed(r, seed, 0x100000000ULL + (uint64_t) (first + c));
     const bool live = c < count;
     uint32_t b = live && bits[c] ? (1u << 29) : (0u - (1u << 29));
-    b += (uint32_t) crng_gauss(r, kKsNoiseM);
+    b += (uint32_t) crng_gauss(r, kKsNoiseM, cdt);
     for (int q0 = 0; q0 < kLwe; q0 += 64) {
         const int nq = kLwe - q0 < 64 ? kLwe - q0 : 64;
         for (int q = 0; q < nq; q++) {
@@ -2141,14 +2138,14 @@ __global__ __launch_bounds__(256) void k_client_phase(const int32_t *__restrict_
 // bit-identical to bk_worker of client_keys.c.  Stage 1: one thread per key bit i draws its stream (noise then mask
 // of each row, sequential by construction).  Stage 2: one workgroup per row adds mask * tlwe_key in Z[X]/(X^N+1)
 // (torusPolynomialAddMulR at tlwe-functions.cpp:35) - exact mod 2^32 in any summation order - and the gadget term.
-__global__ __launch_bounds__(64) void k_client_bk_draw(uint64_t seed, int32_t *__restrict__ bk_coef) {
+__global__ __launch_bounds__(64) void k_client_bk_draw(uint64_t seed, int32_t *__restrict__ bk_coef, const uint64_t *__restrict__ cdt) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= kLwe) return;
     ClientRng r;
     crng_seed(r, seed, 0x10000ULL + (uint64_t) i);
     for (int p = 0; p < kKpl; p++) {
         int32_t *a = bk_coef + (((size_t) i * kKpl + p) * 2 + 0) * kN, *b = a + kN;
-        for (int q = 0; q < kN; q++) b[q] = crng_gauss(r, kBkNoiseM);
+        for (int q = 0; q < kN; q++) b[q] = crng_gauss(r, kBkNoiseM, cdt);
         for (int q = 0; q < kN; q++) a[q] = (int32_t) (uint32_t) (crng_next(r) >> 32);
     }
 }
@@ -2183,14 +2180,15 @@ __global__ __launch_bounds__(256) void k_client_bk_mask(const int32_t *__restric
 
 // keyswitch-key generation (lweCreateKeySwitchKey, lwe-keyswitch-functions.cpp:163-215: ks[i][j][h] = LWE_n encryption
 // of h * s'_i / base^(j+1), h = 0 the trivial zero sample), bit-identical to tfhe_client_keygen, which draws all
-// 24,576 samples from ONE xoshiro256** stream, 636 draws each.  The generator's state transition is linear over GF(2),
+// 24,576 samples from ONE xoshiro256** stream, n + 2 draws each.  The generator's state transition is linear over GF(2),
 // so thread s reaches its starting state by applying the precomputed 256 x 256 bit matrices T^(636 * 2^k) for the
 // set bits k of s (jump[k][row][word]; lane-uniform reads), then draws its sample as the CPU does.
-constexpr int kKsDraws = 6 + kLwe;  // noise (Irwin-Hall: 6 words) + mask
+constexpr int kKsDraws = 2 + kLwe;  // noise (two words: gauss_cdt.h) + mask
 constexpr int kKsJumpBits = 15;     // N * t * (base - 1) = 24,576 samples < 2^15
 __global__ __launch_bounds__(64) void k_client_ks_draw(ClientRng start, const uint64_t *__restrict__ jump,
                                                        const int32_t *__restrict__ lwe_key,
-                                                       const int32_t *__restrict__ tlwe_key, int32_t *__restrict__ ks) {
+                                                       const int32_t *__restrict__ tlwe_key, int32_t *__restrict__ ks,
+                                                       const uint64_t *__restrict__ cdt) {
     __shared__ int32_t tile[64][65];
     const int s0 = blockIdx.x * 64, s = s0 + threadIdx.x;  // sample index = (i * t + j) * 3 + (h - 1); grid covers all
     ClientRng r = start;
@@ -2207,7 +2205,7 @@ __global__ __launch_bounds__(64) void k_client_ks_draw(ClientRng start, const ui
     }
     const int ij = s / 3, h = s % 3 + 1, i = ij / kKsT, j = ij % kKsT;
     uint32_t b = (uint32_t) (tlwe_key[i] * h) << (32 - (j + 1) * kKsBasebit);
-    b += (uint32_t) crng_gauss(r, kKsNoiseM);
+    b += (uint32_t) crng_gauss(r, kKsNoiseM, cdt);
     // rows of the host layout [N][t][4][n+1]; the mask words of 64 samples pass through LDS for coalesced stores
     for (int q0 = 0; q0 < kLwe; q0 += 64) {
         const int nq = kLwe - q0 < 64 ? kLwe - q0 : 64;
@@ -2345,6 +2343,7 @@ struct tfhe_hip_ctx {
     c64 *tw = nullptr;
     PhaseAConsts ka{};
     int arith = TFHE_HIP_ARITH_EXACT;  // tfhe_hip_set_arithmetic
+    uint64_t *cdt = nullptr; // noise table of the client-side kernels (gauss_cdt.h), uploaded on first use
     c64 *twf = nullptr;      // per-lane twiddle image of the FAST mode (fast_core.h)
     c64 *bkf = nullptr;      // FAST mode: [n][6][2][512] in Z_k order, built from bk when the mode is selected
     c64 *bk = nullptr;       // [n][6][2][512] physical order
@@ -2684,6 +2683,7 @@ void tfhe_hip_destroy(tfhe_hip_ctx *c) {
                       &c->jobs_lin}) b->release();
     if (c->tw) (void) hipFree(c->tw);
     if (c->twf) (void) hipFree(c->twf);
+    if (c->cdt) (void) hipFree(c->cdt);
     if (c->bkf) (void) hipFree(c->bkf);
     if (c->bk) (void) hipFree(c->bk);
     if (c->ks) (void) hipFree(c->ks);
@@ -2836,6 +2836,22 @@ extern "C" {
 
 }  // extern "C"
 namespace {
+// the noise table of the client-side kernels: built on the host (fingerprint-checked) and uploaded on first use
+int ensure_cdt(tfhe_hip_ctx *c) {
+    if (c->cdt) return TFHE_HIP_OK;
+    static std::vector<uint64_t> table;
+    static int ok = 0;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        table.resize(GAUSS_CDT_BINS);
+        ok = gauss_cdt_build(table.data(), nullptr);
+    });
+    if (!ok) return fail(TFHE_HIP_ERR_TABLE, "noise table self check failed (host libm rounds erfcl differently)");
+    HIPCHK(hipMalloc((void **) &c->cdt, GAUSS_CDT_BINS * sizeof(uint64_t)));
+    HIPCHK(hipMemcpyAsync(c->cdt, table.data(), GAUSS_CDT_BINS * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TFHE_HIP_OK;
+}
 // zeroes a device region that held secret key material when the enclosing function leaves, whichever way it leaves
 struct DeviceWipe {
     tfhe_hip_ctx *c;
@@ -2859,6 +2875,7 @@ int tfhe_hip_keygen_cloud(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key
                           int32_t *bk_coef_out, int32_t *ks_out) {
     if (int r = check_ctx(c, false)) return r;
     if (!lwe_key || !tlwe_key) return fail(TFHE_HIP_ERR_ARG, "null key pointer");
+    if (int r = ensure_cdt(c)) return r;
     c->have_keys = false;
     static std::vector<BitMat> jump;  // depends on the parameter set only
     static std::once_flag once;
@@ -2879,7 +2896,7 @@ int tfhe_hip_keygen_cloud(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key
     HIPCHK(hipMemsetAsync(c->misc.p, 0, kKsHostElems * sizeof(int32_t), c->stream));  // the h = 0 rows
     static_assert(kN * kKsT * 3 % 64 == 0, "whole workgroups of samples");
     hipLaunchKernelGGL(k_client_ks_draw, dim3(kN * kKsT * 3 / 64), dim3(64), 0, c->stream, start, (const uint64_t *) d_jump,
-                       (const int32_t *) d_lwe, (const int32_t *) d_tlwe, (int32_t *) c->misc.p);
+                       (const int32_t *) d_lwe, (const int32_t *) d_tlwe, (int32_t *) c->misc.p, (const uint64_t *) c->cdt);
     HIPCHK(hipGetLastError());
     if (ks_out) HIPCHK(hipMemcpyAsync(ks_out, c->misc.p, kKsHostElems * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     int r = pack_ks_from_misc(c);
@@ -2894,6 +2911,7 @@ int tfhe_hip_keygen_bk(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key, c
     if (int r = check_ctx(c, false)) return r;
     if (!lwe_key || !tlwe_key) return fail(TFHE_HIP_ERR_ARG, "null key pointer");
     if (!ks && !c->kl) return fail(TFHE_HIP_ERR_ARG, "no keyswitch key given and none on the device");
+    if (int r = ensure_cdt(c)) return r;
     c->have_keys = false;
     const size_t coef_bytes = (size_t) kLwe * kKpl * 2 * kN * sizeof(int32_t);
     if (!c->bk) HIPCHK(hipMalloc((void **) &c->bk, kBkBytes));
@@ -2904,7 +2922,8 @@ int tfhe_hip_keygen_bk(tfhe_hip_ctx *c, uint64_t seed, const int32_t *lwe_key, c
     wipe.arm(d_lwe, (kLwe + kN) * sizeof(int32_t));
     HIPCHK(hipMemcpyAsync(d_lwe, lwe_key, kLwe * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_tlwe, tlwe_key, kN * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_client_bk_draw, dim3((kLwe + 63) / 64), dim3(64), 0, c->stream, seed, (int32_t *) c->misc.p);
+    hipLaunchKernelGGL(k_client_bk_draw, dim3((kLwe + 63) / 64), dim3(64), 0, c->stream, seed, (int32_t *) c->misc.p,
+                       (const uint64_t *) c->cdt);
     hipLaunchKernelGGL(k_client_bk_mask, dim3(kLwe * kKpl), dim3(256), 0, c->stream, (const int32_t *) d_lwe,
                        (const int32_t *) d_tlwe, (int32_t *) c->misc.p);
     HIPCHK(hipGetLastError());
@@ -3541,6 +3560,7 @@ int tfhe_hip_encrypt_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, uint64_t seed, i
     if (count < 0 || first_index < 0 || (count > 0 && (!d_out || !lwe_key || !bits)))
         return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
     if (count == 0) return TFHE_HIP_OK;
+    if (int r = ensure_cdt(c)) return r;
     HIPCHK(c->misc.reserve(kLwe * sizeof(int32_t) + (size_t) count));
     int32_t *d_key = (int32_t *) c->misc.p;
     uint8_t *d_bits = (uint8_t *) (d_key + kLwe);
@@ -3549,7 +3569,8 @@ int tfhe_hip_encrypt_batch_dev(tfhe_hip_ctx *c, int32_t *d_out, uint64_t seed, i
     HIPCHK(hipMemcpyAsync(d_key, lwe_key, kLwe * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_bits, bits, (size_t) count, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_client_encrypt, dim3((unsigned) ((count + 63) / 64)), dim3(64), 0, c->stream, seed,
-                       (const int32_t *) d_key, (const uint8_t *) d_bits, (long long) first_index, (long long) count, d_out);
+                       (const int32_t *) d_key, (const uint8_t *) d_bits, (long long) first_index, (long long) count, d_out,
+                       (const uint64_t *) c->cdt);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));  // misc is reused by other calls
     return TFHE_HIP_OK;
