@@ -151,21 +151,26 @@ def side_bench(args, torch, dev, rank, world):
         kernel = "k_blind_rotate<%s> x 2" % mode
     else:
         B = 1 << 16
-        n = PR.N if args.workload == "fft" else 2 * PR.N
+        n = {"fft": PR.N, "fft2048": 2 * PR.N, "fft512": PR.N // 2}[args.workload]
         rng = np.random.default_rng(6)
         ha = rng.integers(-2 * n, 2 * n, (B, n)).astype(np.int32)   # src/test/test-multiplication.cpp:41-44
         hb = rng.integers(-2**31, 2**31, (B, n)).astype(np.int32)
         a, b = torch.from_numpy(ha).to(dev), torch.from_numpy(hb).to(dev)
         d_out = torch.empty((B, n), dtype=torch.int32, device=dev)
+        # algorithmic work of one product in its minimal folded form: two forward + one inverse N/2-point transform
+        # (twist 6 + 5 log2(N/2) flop per point) and N/2 complex products
+        flop = (3 * ((n // 2) * 6 + 5 * (n // 2) * int(np.log2(n // 2))) + (n // 2) * 6.0) * B
+        single = lambda: eng.negacyclic_mul_n_dev(n, d_out, a, b, B)  # noqa: E731  one N/2-point transform pair per product
         if args.workload == "fft":
-            run = lambda: eng.negacyclic_mul_dev(d_out, a, b, B)  # noqa: E731
-            flop, kernel = FLOP_PER_FFT_PRODUCT * B, "k_poly_mul%s" % ("_fast" if mode == "fast" else "")
-        else:   # N = 2048 (no reference transform exists): even/odd split into N = 1024 transforms - FAST: one fused kernel,
-            # four forward + two inverse; EXACT: four separate N = 1024 products.  Algorithmic work in either mode: the
-            # minimal folded form at N = 2048, two forward + one inverse 1024-point transform + 1024 complex products
+            run = (lambda: eng.negacyclic_mul_dev(d_out, a, b, B)) if args.fft_kernel != "single" else single  # noqa: E731
+            kernel = "k_poly_mul%s" % ("_fast" if mode == "fast" else "") if args.fft_kernel != "single" else "k_n_mul<9>"
+        elif args.workload == "fft2048" and args.fft_kernel == "fused":
+            # N = 2048 with the last radix-2 level folded into the pointwise product: four forward + two inverse 512-point
+            # transforms (FAST: one kernel; EXACT: four separate N = 1024 products)
             run = lambda: eng.negacyclic_mul2048_dev(d_out, a, b, B)  # noqa: E731
-            flop = (3 * (1024 * 6 + 5 * 1024 * 10) + 1024 * 6.0) * B
             kernel = "k_poly_mul2048_fast" if mode == "fast" else "k_split2048 + k_poly_mul + k_combine2048"
+        else:
+            run, kernel = single, "k_n_mul<%d>" % int(np.log2(n // 2))
         unit, per_step, name = "products/s", B, "negacyclic IntPolynomial x TorusPolynomial FFT products/sec, N=%d" % n
     for _ in range(args.warmup):
         run()
@@ -192,13 +197,13 @@ def side_bench(args, torch, dev, rank, world):
         else:
             orc = Oracle()
             ref = _ref_lib() if args.workload == "fft" else None
-            per = 2000 if args.workload == "fft" else 60
+            per = 2000 if args.workload == "fft" else (60 if args.workload == "fft2048" else 600)
             cnt = threads * per
             out = np.zeros((cnt, got.shape[1]), np.int32)
 
             def work(t):
                 for i in range(t * per, (t + 1) * per):
-                    if args.workload == "fft2048":   # the reference's exact product (multiplication.cpp:31-43), N as argument
+                    if args.workload != "fft":   # the reference's exact product (multiplication.cpp:31-43), N as argument
                         orc.lib.oracle_mulNaive(P(out[i]), P(ha[i]), P(hb[i]), ctypes_i32(got.shape[1]))
                     elif ref is not None:
                         ref.ref_mul_fft(P(out[i]), P(ha[i]), P(hb[i]))
@@ -211,23 +216,34 @@ def side_bench(args, torch, dev, rank, world):
                 list(ex.map(work, range(threads)))
             cdt = time.perf_counter() - t1
             diff = np.abs((got[:cnt].astype(np.int64) - out.astype(np.int64) + 2**31) % 2**32 - 2**31).max()
-            assert diff <= (2 if args.workload == "fft2048" else (0 if mode == "exact" else 1)), diff
+            assert diff <= (2 if args.workload == "fft2048" else (0 if mode == "exact" and kernel == "k_poly_mul" else 1)), diff
             cpu = {"value": cnt / cdt, "unit": unit, "cores": threads, "host_cores_available": len(os.sched_getaffinity(0)),
                    "kind": "reference" if ref is not None else "port",
                    "sample": "%d products on %d threads, %.1f s wall; %s; GPU results within %d LSB of them" % (
                        cnt, threads, cdt, "torusPolynomialMultFFT (polynomials.cpp:241)" if args.workload == "fft" else
                        "exact schoolbook product torusPolynomialMultNaive_aux (multiplication.cpp:31-43): the reference "
-                       "has no N = 2048 transform", int(diff))}
+                       "has no transform at this N", int(diff))}
     if args.workload == "mux":
         dec, _ = client.decrypt(keys, got)
         assert np.array_equal(dec, np.where(bits[0] == 1, bits[1], bits[2])), "MUX outputs decrypt wrongly"
+        roof = _roofline(kernel, flop, float(np.mean(kms)),
+                         "FP64 vector ALUs; launch = the FP64 kernels of one call (HIP events on the engine's stream)")
+    else:
+        # 6.7 flop per byte x 8 TB/s = 54 TFLOP/s < the 78.6 TFLOP/s FP64 roof: the product kernels are HBM-bound (operands
+        # and results exceed the 256 MB Infinity Cache at 2^16 products).  Algorithmic bytes: two operands in, one result out.
+        launch_ms = float(np.mean(kms))
+        bytes_per_launch = 3.0 * n * 4 * B
+        gbs = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                "traffic": None, "bytes_per_launch": bytes_per_launch, "bytes_per_product": 3 * n * 4, "launch_ms": launch_ms,
+                "fp64": {"achieved_tflops": flop / (launch_ms * 1e-3) / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                         "frac": flop / (launch_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "flop_per_launch": flop}}
     print(json.dumps({"metric": name, "value": per_step * args.steps / dt, "unit": unit, "n_gpus": 1,
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": "%s, %s arithmetic (BASELINE configs[4])" % (args.workload, mode.upper()),
+                      "config": {"workload": "%s, %s arithmetic, kernel %s (BASELINE configs[4])" % (args.workload, mode.upper(), kernel),
                                  "arithmetic": mode, "batch": per_step},
-                      "roofline": _roofline(kernel, flop, float(np.mean(kms)),
-                                            "FP64 vector ALUs; launch = the FP64 kernels of one call (HIP events on the engine's stream)"),
+                      "roofline": roof,
                       "cpu_baseline": cpu}), flush=True)
     eng.close()
 
@@ -366,9 +382,12 @@ def main():
                     help="gates per GPU per step; default 16384 on one GPU (BASELINE configs[1]) and 2^20 / 8 = 131072 on "
                          "several (on 8 GPUs the job is BASELINE configs[2]: 2^20 gates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="nand", choices=["nand", "mux", "fft", "fft2048", "adder", "comparator"],
+    ap.add_argument("--workload", default="nand", choices=["nand", "mux", "fft", "fft2048", "fft512", "adder", "comparator"],
                     help="nand: BASELINE configs[1] (default, the headline); adder / comparator: configs[3] levelized "
                          "32-bit circuits; mux / fft / fft2048: configs[4] side benches")
+    ap.add_argument("--fft-kernel", default="auto", choices=["auto", "single", "fused"],
+                    help="fft workloads: single = one N/2-point transform pair per product (k_n_mul, any N); fused = N=2048 only, "
+                         "last level folded into the product (k_poly_mul2048_fast); auto = the N=1024 kernel of the mode / single")
     ap.add_argument("--instances", type=int, default=4096, help="adder workload: independent adder instances")
     ap.add_argument("--arith", default="both", choices=["exact", "fast", "both"],
                     help="arithmetic of the FP64 stage (tfhe_hip_set_arithmetic): exact = bit-identical to the reference; "

@@ -237,6 +237,41 @@ int tfhe_hip_negacyclic_mul2048_batch(tfhe_hip_ctx *ctx, int32_t *out, const int
 int tfhe_hip_negacyclic_mul2048_batch_dev(tfhe_hip_ctx *ctx, int32_t *d_out, const int32_t *d_ipolys,
                                           const int32_t *d_tpolys, int64_t count);
 
+/* ---- TGSW / TLWE operations with N, k and the gadget (l, Bgbit) as run-time parameters ------------------
+ * The reference's TGSW / TLWE layer reads N, k, l, Bgbit from its parameter structs (TGswParams / TLweParams, tgsw.cpp:7-27;
+ * its own tests run N = 512 / 1024 / 2048, k = 1 / 2, (l, Bgbit) = (4, 8) / (3, 10): src/test/tgsw_fft_test.cpp:28-35).
+ * Here: N in {512, 1024, 2048} - one real N/2-point folded transform per polynomial at every N, no composition of smaller
+ * products -, k in {1, 2}, any gadget with l * Bgbit <= 32; the same in both arithmetic modes (this fork compiles the
+ * reference's transform for N = 1024 only, tfhe_core.h:14, so there is no other-N arithmetic to be bit-identical to).
+ * Parity: the reference's exact products (torusPolynomialMultNaive_aux, multiplication.cpp:31-43, N at run time) and its
+ * generic decomposition (Torus32PolynomialDecompH_old, tgsw-functions.cpp:277-293) - products within 1 LSB (2 at N = 2048)
+ * as src/test/test-multiplication.cpp:66-77, external products within a few LSB of the exact sum of row products
+ * (the identity src/test/tgsw_fft_test.cpp:245-285 checks), decomposition exact.  Layouts as above with N, k, l general:
+ * TLWE sample int32[k+1][N]; TGSW sample int32[(k+1)l][k+1][N] (row i*l + p = digit p of polynomial i, tgsw-functions.cpp
+ * :264-269); its FFT form double[(k+1)l][k+1][N/2][2] = coefsC (P(w^(2i+1)), w = exp(i pi / N)). */
+/* torusPolynomialMultFFT (polynomials.cpp:241) at ring dimension N */
+int tfhe_hip_negacyclic_mul_n_batch(tfhe_hip_ctx *ctx, int32_t N, int32_t *out, const int32_t *ipolys, const int32_t *tpolys,
+                                    int64_t count);
+int tfhe_hip_negacyclic_mul_n_batch_dev(tfhe_hip_ctx *ctx, int32_t N, int32_t *d_out, const int32_t *d_ipolys,
+                                        const int32_t *d_tpolys, int64_t count);
+/* IntPolynomial_ifft / TorusPolynomial_ifft / TorusPolynomial_fft (polynomials.cpp:347,364,378) at ring dimension N;
+ * tGswToFFTConvert (tgsw-fft-operations.cpp:52-57) = tfhe_hip_torus_ifft_n_batch over the (k+1)l(k+1) polynomials */
+int tfhe_hip_int_ifft_n_batch(tfhe_hip_ctx *ctx, int32_t N, double *spectra, const int32_t *polys, int64_t count);
+int tfhe_hip_torus_ifft_n_batch(tfhe_hip_ctx *ctx, int32_t N, double *spectra, const int32_t *polys, int64_t count);
+int tfhe_hip_torus_fft_n_batch(tfhe_hip_ctx *ctx, int32_t N, int32_t *polys, const double *spectra, int64_t count);
+/* Torus32PolynomialDecompH_old (tgsw-functions.cpp:277-293): polys[count][N] -> out[count][l][N] (any N >= 1) */
+int tfhe_hip_tgsw_decomp_n_batch(tfhe_hip_ctx *ctx, int32_t N, int32_t l, int32_t Bgbit, int32_t *out, const int32_t *polys,
+                                 int64_t count);
+/* tGswFFTExternMulToTLwe (tgsw-fft-operations.cpp:92-120) / tGswExternMulToTLwe (tgsw-functions.cpp:157-170):
+ * acc[g] <- gsw[index[g]] (*) acc[g], acc int32[count][k+1][N] in/out */
+int tfhe_hip_tgsw_fft_extern_mul_n_batch(tfhe_hip_ctx *ctx, int32_t N, int32_t k, int32_t l, int32_t Bgbit, int32_t *acc,
+                                         const double *gsw_fft, const int32_t *gsw_index, int64_t ngsw, int64_t count);
+int tfhe_hip_tgsw_extern_mul_n_batch(tfhe_hip_ctx *ctx, int32_t N, int32_t k, int32_t l, int32_t Bgbit, int32_t *acc,
+                                     const int32_t *tgsw, const int32_t *tgsw_index, int64_t ntgsw, int64_t count);
+/* tLweAddMulRTo (tlwe-functions.cpp:191-197): result[g] += poly[g] * sample[g]; result, sample int32[count][k+1][N] */
+int tfhe_hip_tlwe_addmul_r_n_batch(tfhe_hip_ctx *ctx, int32_t N, int32_t k, int32_t *result, const int32_t *poly,
+                                   const int32_t *sample, int64_t count);
+
 /* ---- compiled netlist (levels without host round-trips) ---------------------------------------
  * A whole levelized circuit over a device-resident pool: `gates` holds the levels back to back ({gate, out, a, b, c}
  * rows as for tfhe_hip_gate_level_dev), level_counts[l] the number of gates of level l.  Every level is validated

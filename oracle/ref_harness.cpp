@@ -545,3 +545,31 @@ void ref_tlwe_addmul_r(int32_t *result /*[2][N] in/out*/, const int32_t *poly /*
     delete_IntPolynomial(p); delete_TLweSample(s); delete_TLweSample(r);
 }
 }  // extern "C"
+
+// ---- run-time N, l, Bgbit ----------------------------------------------------------------------------
+// What the reference can run at other parameters than its compiled-in set: the generic gadget decomposition
+// (Torus32PolynomialDecompH_old, tgsw-functions.cpp:277-293; its structs hold Value_N = 1024 coefficients, so N <= 1024) with
+// a TGswParams of the caller's l and Bgbit (tgsw.cpp:7-27), and the exact schoolbook product torusPolynomialMultNaive_aux
+// (multiplication.cpp:31-43) on raw arrays of any N.  Its composed external product goes through the hard-wired
+// decomposition and the N = 1024 transform and cannot.
+void torusPolynomialMultNaive_aux(Torus32 *__restrict result, const int32_t *__restrict poly1, const Torus32 *__restrict poly2,
+                                  const int32_t N);
+extern "C" {
+int refn_decomp(int32_t *out /*[l][n]*/, const int32_t *poly /*n*/, int32_t n, int32_t l, int32_t Bgbit) {
+    if (n > N_) return -1;
+    TLweParams *tp = new_TLweParams(n, 1, 0., 1.);
+    TGswParams *gp = new_TGswParams(l, Bgbit, tp);
+    IntPolynomial *r = new_IntPolynomial_array(l);
+    TorusPolynomial *p = new_TorusPolynomial();
+    memset(p->coefsT, 0, sizeof(p->coefsT));
+    memcpy(p->coefsT, poly, sizeof(int32_t) * n);
+    Torus32PolynomialDecompH_old(r, p, gp);
+    for (int q = 0; q < l; q++) memcpy(out + (size_t) q * n, r[q].coefs, sizeof(int32_t) * n);
+    delete_TorusPolynomial(p); delete_IntPolynomial_array(l, r);
+    delete_TGswParams(gp); delete_TLweParams(tp);
+    return 0;
+}
+void refn_mul_naive(int32_t *out, const int32_t *ipoly, const int32_t *tpoly, int32_t n) {
+    torusPolynomialMultNaive_aux(out, ipoly, tpoly, n);
+}
+}  // extern "C"

@@ -534,3 +534,41 @@ int32_t oracle_lwePhase(const int32_t *ct, const int32_t *key, int32_t n) {
     for (int i = 0; i < n; i++) axs += (uint32_t) ct[i] * (uint32_t) key[i];
     return (int32_t) ((uint32_t) ct[n] - axs);
 }
+
+/* ---- the TGSW / TLWE layer with its parameters at run time ------------------------------------------
+ * The reference's structs carry N, k, l, Bgbit (tgsw.cpp:7-27, tlwe.cpp); its generic functions loop over them.  Its
+ * transform is compiled for N = 1024 only, so the products below are its EXACT schoolbook products
+ * (torusPolynomialMultNaive_aux, multiplication.cpp:31-43, N a run-time argument): what any transform-based product must
+ * equal up to its rounding (src/test/tgsw_fft_test.cpp:245-285 checks exactly this identity with Karatsuba). */
+/* Torus32PolynomialDecompH_old, tgsw-functions.cpp:277-293, with offset / maskMod / halfBg of tgsw.cpp:7-27 */
+void oracle_decompH_n(int32_t *out /*[l][N]*/, const int32_t *poly /*N*/, int32_t n, int32_t l, int32_t Bgbit) {
+    const uint32_t halfBg = 1u << (Bgbit - 1), maskMod = (1u << Bgbit) - 1;
+    uint32_t temp1 = 0;
+    for (int i = 0; i < l; i++) temp1 += 1u << (32 - (i + 1) * Bgbit);
+    const uint32_t offset = temp1 * halfBg;
+    for (int j = 0; j < n; j++) {
+        const uint32_t temp0 = (uint32_t) poly[j] + offset;
+        for (int p = 0; p < l; p++) out[p * n + j] = (int32_t) (((temp0 >> (32 - (p + 1) * Bgbit)) & maskMod) - halfBg);
+    }
+}
+/* tLweAddMulRTo, tlwe-functions.cpp:191-197: result[i] += p * sample[i], i <= k, every product exact */
+void oracle_tLweAddMulRTo_n(int32_t *result /*[k+1][N]*/, const int32_t *p /*N*/, const int32_t *sample /*[k+1][N]*/, int32_t n,
+                            int32_t k) {
+    int32_t *prod = (int32_t *) malloc(sizeof(int32_t) * (size_t) n);
+    for (int i = 0; i <= k; i++) {
+        oracle_mulNaive(prod, p, sample + (size_t) i * n, n);
+        for (int j = 0; j < n; j++) result[(size_t) i * n + j] = (int32_t) ((uint32_t) result[(size_t) i * n + j] + (uint32_t) prod[j]);
+    }
+    free(prod);
+}
+/* tGswExternMulToTLwe, tgsw-functions.cpp:157-170: decomposition of all k+1 polynomials (tGswTLweDecompH, :264-269: row
+ * i*l + p = digit p of polynomial i), accumulator cleared, then the kpl row products added */
+void oracle_tgswExternMulToTLwe_n(int32_t *acc /*[k+1][N] in/out*/, const int32_t *tgsw /*[(k+1)l][k+1][N]*/, int32_t n, int32_t k,
+                                  int32_t l, int32_t Bgbit) {
+    const int kpl = (k + 1) * l;
+    int32_t *dec = (int32_t *) malloc(sizeof(int32_t) * (size_t) kpl * n);
+    for (int i = 0; i <= k; i++) oracle_decompH_n(dec + (size_t) i * l * n, acc + (size_t) i * n, n, l, Bgbit);
+    memset(acc, 0, sizeof(int32_t) * (size_t) (k + 1) * n);
+    for (int i = 0; i < kpl; i++) oracle_tLweAddMulRTo_n(acc, dec + (size_t) i * n, tgsw + (size_t) i * (k + 1) * n, n, k);
+    free(dec);
+}

@@ -81,6 +81,13 @@ void oracle_gate_batch(const oracle_keys *k, int32_t gate, int32_t *out, const i
 /* client-side helper for checks: phase = b - <a,s> */
 int32_t oracle_lwePhase(const int32_t *ct, const int32_t *key, int32_t n);
 
+/* run-time N, k, l, Bgbit: exact (schoolbook) products */
+void oracle_decompH_n(int32_t *out /*[l][N]*/, const int32_t *poly /*N*/, int32_t N, int32_t l, int32_t Bgbit);
+void oracle_tLweAddMulRTo_n(int32_t *result /*[k+1][N]*/, const int32_t *p /*N*/, const int32_t *sample /*[k+1][N]*/, int32_t N,
+                            int32_t k);
+void oracle_tgswExternMulToTLwe_n(int32_t *acc /*[k+1][N] in/out*/, const int32_t *tgsw /*[(k+1)l][k+1][N]*/, int32_t N, int32_t k,
+                                  int32_t l, int32_t Bgbit);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,6 +169,24 @@ class Oracle:
                                    ctypes.c_int32(nthreads))
         return out
 
+    # run-time N, k, l, Bgbit (exact products)
+    def decomp_n(self, poly, n_, l, bgbit):
+        poly = i32(poly)
+        out = np.empty((l, n_), np.int32)
+        self.lib.oracle_decompH_n(P(out), P(poly), ctypes.c_int32(n_), ctypes.c_int32(l), ctypes.c_int32(bgbit))
+        return out
+
+    def tlwe_addmul_r_n(self, result, poly, sample, n_, k):
+        res = i32(result).copy()
+        self.lib.oracle_tLweAddMulRTo_n(P(res), P(i32(poly)), P(i32(sample)), ctypes.c_int32(n_), ctypes.c_int32(k))
+        return res
+
+    def tgsw_extern_mul_n(self, acc, tgsw, n_, k, l, bgbit):
+        acc = i32(acc).copy()
+        self.lib.oracle_tgswExternMulToTLwe_n(P(acc), P(i32(tgsw)), ctypes.c_int32(n_), ctypes.c_int32(k), ctypes.c_int32(l),
+                                              ctypes.c_int32(bgbit))
+        return acc
+
     def phase(self, ct, key):
         ct, key = i32(ct), i32(key)
         self.lib.oracle_lwePhase.restype = ctypes.c_int32

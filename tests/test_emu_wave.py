@@ -24,3 +24,14 @@ def test_fast_mode_arithmetic_on_host(tmp_path):
                     "-Wl,-rpath," + os.path.join(ROOT, "oracle")], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "EMU FAST OK" in out
+
+
+def test_generic_dimension_transforms_on_host(tmp_path):
+    """tests/emu/emu_nfft.cpp: the per-lane routines of tfhe_amd/csrc/nfft_core.h (N = 512 / 1024 / 2048) against the
+    direct evaluation of the transform and the reference's exact products"""
+    exe = str(tmp_path / "emu_nfft")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-mfma", "-ffp-contract=off", "-o", exe,
+                    os.path.join(ROOT, "tests", "emu", "emu_nfft.cpp"), "-L" + os.path.join(ROOT, "oracle"), "-loracle",
+                    "-Wl,-rpath," + os.path.join(ROOT, "oracle")], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "EMU NFFT OK" in out

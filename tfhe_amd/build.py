@@ -37,7 +37,8 @@ def _suffix(lam):
 def build_hip(force=False, lam=128):
     out = os.path.join(ROOT, "tfhe_amd", "libtfhe_hip%s.so" % _suffix(lam))
     srcs = [os.path.join(CSRC, "tfhe_hip.hip"), os.path.join(CSRC, "br_core.h"),
-            os.path.join(CSRC, "fast_core.h"), os.path.join(CSRC, "gauss_cdt.h"), os.path.join(CSRC, "compat_libtfhe.cpp"), os.path.join(CSRC, "wire_io.cpp"),
+            os.path.join(CSRC, "fast_core.h"), os.path.join(CSRC, "gauss_cdt.h"), os.path.join(CSRC, "nfft_core.h"), os.path.join(CSRC, "nk_ops.h"),
+            os.path.join(CSRC, "compat_libtfhe.cpp"), os.path.join(CSRC, "wire_io.cpp"),
             os.path.join(CSRC, "internal.h"), os.path.join(ROOT, "include", "tfhe_hip.h"),
             os.path.join(ROOT, "include", "tfhe_hip_compat.h"), os.path.join(ROOT, "include", "tfhe_hip_io.h")]
     srcs = [s for s in srcs if os.path.exists(s)]

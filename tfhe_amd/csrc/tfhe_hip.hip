@@ -2343,6 +2343,7 @@ struct tfhe_hip_ctx {
     c64 *tw = nullptr;
     PhaseAConsts ka{};
     int arith = TFHE_HIP_ARITH_EXACT;  // tfhe_hip_set_arithmetic
+    c64 *ntab[3] = {nullptr, nullptr, nullptr};  // transform tables for N = 512 / 1024 / 2048 (nk_ops.h), built on first use
     uint64_t *cdt = nullptr; // noise table of the client-side kernels (gauss_cdt.h), uploaded on first use
     c64 *twf = nullptr;      // per-lane twiddle image of the FAST mode (fast_core.h)
     c64 *bkf = nullptr;      // FAST mode: [n][6][2][512] in Z_k order, built from bk when the mode is selected
@@ -2684,6 +2685,8 @@ void tfhe_hip_destroy(tfhe_hip_ctx *c) {
     if (c->tw) (void) hipFree(c->tw);
     if (c->twf) (void) hipFree(c->twf);
     if (c->cdt) (void) hipFree(c->cdt);
+    for (c64 *t : c->ntab)
+        if (t) (void) hipFree(t);
     if (c->bkf) (void) hipFree(c->bkf);
     if (c->bk) (void) hipFree(c->bk);
     if (c->ks) (void) hipFree(c->ks);
@@ -4013,3 +4016,5 @@ int tfhe_hip_copy_from_dev(tfhe_hip_ctx *c, void *dst, const void *src, size_t b
 }
 
 }  // extern "C"
+
+#include "nk_ops.h"

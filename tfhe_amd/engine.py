@@ -71,6 +71,9 @@ EXPORTS = [
     "tfhe_hip_group_load_keys_coef", "tfhe_hip_group_load_keys_fft", "tfhe_hip_group_set_arithmetic",
     "tfhe_hip_group_gate_batch", "tfhe_hip_group_key_path", "tfhe_hip_keys_fingerprint",
     "tfhe_hip_tgsw_fft_extern_mul_batch", "tfhe_hip_tgsw_extern_mul_batch", "tfhe_hip_tlwe_addmul_r_batch",
+    "tfhe_hip_negacyclic_mul_n_batch", "tfhe_hip_negacyclic_mul_n_batch_dev", "tfhe_hip_int_ifft_n_batch",
+    "tfhe_hip_torus_ifft_n_batch", "tfhe_hip_torus_fft_n_batch", "tfhe_hip_tgsw_decomp_n_batch",
+    "tfhe_hip_tgsw_fft_extern_mul_n_batch", "tfhe_hip_tgsw_extern_mul_n_batch", "tfhe_hip_tlwe_addmul_r_n_batch",
 ]
 
 
@@ -527,3 +530,61 @@ class Engine:
         self._chk(self.lib.tfhe_hip_negacyclic_mul_batch(self.ctx, _p(out), _p(a), _p(b), ctypes.c_int64(a.shape[0])),
                   "negacyclic_mul_batch")
         return out
+
+    # ---- run-time N, k, l, Bgbit ----
+    def negacyclic_mul_n(self, N, ipolys, tpolys):
+        a = np.ascontiguousarray(ipolys, np.int32).reshape(-1, N)
+        b = np.ascontiguousarray(tpolys, np.int32).reshape(-1, N)
+        assert a.shape == b.shape
+        out = np.empty_like(a)
+        self._chk(self.lib.tfhe_hip_negacyclic_mul_n_batch(self.ctx, ctypes.c_int32(N), _p(out), _p(a), _p(b),
+                                                           ctypes.c_int64(a.shape[0])), "negacyclic_mul_n_batch")
+        return out
+
+    def negacyclic_mul_n_dev(self, N, out, ipolys, tpolys, count):
+        self._chk(self.lib.tfhe_hip_negacyclic_mul_n_batch_dev(self.ctx, ctypes.c_int32(N), self._dptr(out), self._dptr(ipolys),
+                                                               self._dptr(tpolys), ctypes.c_int64(count)),
+                  "negacyclic_mul_n_batch_dev")
+
+    def ifft_n(self, N, polys, torus=True):
+        x = np.ascontiguousarray(polys, np.int32).reshape(-1, N)
+        out = np.empty((x.shape[0], N // 2, 2), np.float64)
+        fn = self.lib.tfhe_hip_torus_ifft_n_batch if torus else self.lib.tfhe_hip_int_ifft_n_batch
+        self._chk(fn(self.ctx, ctypes.c_int32(N), _p(out), _p(x), ctypes.c_int64(x.shape[0])), "ifft_n_batch")
+        return out
+
+    def fft_n(self, N, spectra):
+        s = np.ascontiguousarray(spectra, np.float64).reshape(-1, N // 2, 2)
+        out = np.empty((s.shape[0], N), np.int32)
+        self._chk(self.lib.tfhe_hip_torus_fft_n_batch(self.ctx, ctypes.c_int32(N), _p(out), _p(s), ctypes.c_int64(s.shape[0])),
+                  "torus_fft_n_batch")
+        return out
+
+    def decomp_n(self, N, l, Bgbit, polys):
+        x = np.ascontiguousarray(polys, np.int32).reshape(-1, N)
+        out = np.empty((x.shape[0], l, N), np.int32)
+        self._chk(self.lib.tfhe_hip_tgsw_decomp_n_batch(self.ctx, ctypes.c_int32(N), ctypes.c_int32(l), ctypes.c_int32(Bgbit), _p(out),
+                                                        _p(x), ctypes.c_int64(x.shape[0])), "tgsw_decomp_n_batch")
+        return out
+
+    def tgsw_extern_mul_n(self, N, k, l, Bgbit, acc, gsw, index, fft=False):
+        """acc int32[count][k+1][N]; gsw: int32[ngsw][(k+1)l][k+1][N] (fft=False) or float64[ngsw][(k+1)l][k+1][N/2][2]"""
+        acc = np.ascontiguousarray(acc, np.int32).reshape(-1, k + 1, N).copy()
+        idx = np.ascontiguousarray(index, np.int32).reshape(-1)
+        if fft:
+            g = np.ascontiguousarray(gsw, np.float64).reshape(-1, (k + 1) * l, k + 1, N // 2, 2)
+            fn = self.lib.tfhe_hip_tgsw_fft_extern_mul_n_batch
+        else:
+            g = np.ascontiguousarray(gsw, np.int32).reshape(-1, (k + 1) * l, k + 1, N)
+            fn = self.lib.tfhe_hip_tgsw_extern_mul_n_batch
+        self._chk(fn(self.ctx, ctypes.c_int32(N), ctypes.c_int32(k), ctypes.c_int32(l), ctypes.c_int32(Bgbit), _p(acc), _p(g),
+                     _p(idx), ctypes.c_int64(g.shape[0]), ctypes.c_int64(acc.shape[0])), "tgsw_extern_mul_n_batch")
+        return acc
+
+    def tlwe_addmul_r_n(self, N, k, result, poly, sample):
+        res = np.ascontiguousarray(result, np.int32).reshape(-1, k + 1, N).copy()
+        p = np.ascontiguousarray(poly, np.int32).reshape(-1, N)
+        s = np.ascontiguousarray(sample, np.int32).reshape(-1, k + 1, N)
+        self._chk(self.lib.tfhe_hip_tlwe_addmul_r_n_batch(self.ctx, ctypes.c_int32(N), ctypes.c_int32(k), _p(res), _p(p), _p(s),
+                                                          ctypes.c_int64(res.shape[0])), "tlwe_addmul_r_n_batch")
+        return res
