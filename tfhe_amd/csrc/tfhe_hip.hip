@@ -198,6 +198,7 @@ struct BrArgs {
     int32_t *acc_io;       // MODE_RAW / MODE_EXTMUL: TLWE accumulators [B][2][N], in/out
     const int32_t *bara;   // MODE_RAW: [B][n] rotation amounts; MODE_EXTMUL: [B] key index
     const c64 *bk;         // [n][6][2][8][64] physical slot order
+    int bk_bytes;          // size of the key array behind bk (buffer-resource bound of the FAST kernel's key loads)
     const c64 *tw;         // per-lane twiddle image, kTwLaneEntries
     PhaseAConsts ka;       // in-register-phase twiddles (scalar registers)
     long long B;
@@ -232,6 +233,25 @@ __device__ __forceinline__ void load_col(c64 (&kb)[8], const c64 *row) {
 #else
 #pragma unroll
     for (int r = 0; r < 8; r++) kb[r] = row[r * 64];
+#endif
+}
+// the same through a buffer resource: address = base (descriptor) + lane offset (one VGPR, set once) + uniform offset of
+// the column and r KB (an SGPR, computed on the scalar unit), instead of a 64-bit address per lane and load
+struct KeyBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;  // lane * 16
+};
+__device__ __forceinline__ void load_col_buf(c64 (&kb)[8], const KeyBuf &k, int soff /*byte offset of the column, uniform*/) {
+#if TFHE_HIP_KO & 4
+#pragma unroll
+    for (int r = 0; r < 8; r++) kb[r] = c64{0.25 + r, 0.5 - (double) (soff & 1)};
+#else
+    const int s0 = __builtin_amdgcn_readfirstlane(soff);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {  // the r KB go into the scalar offset too: one lane-offset register serves all loads
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(k.rsrc, k.voff, s0 + r * 1024, 0);
+        kb[r] = __builtin_bit_cast(c64, w);
+    }
 #endif
 }
 // halves (h = fixed y3) of the inverse transposes through the 8 KB scratch
@@ -520,7 +540,7 @@ __device__ __forceinline__ void wave_inv_fast(int32_t (&lo)[8], int32_t (&hi)[8]
 template <bool ROTATE>
 __device__ __forceinline__ void fwd_step_fast(const int t, c64 (&v)[8], const c64 (&pv)[8], c64 (&tmpa)[2][8],
                                               c64 (&kb)[8], uint32_t (&tlo)[8], uint32_t (&thi)[8], const int32_t *acc,
-                                              c64 *scratch, int lane, int bara, const c64 *bki, const PhaseAConsts &twu,
+                                              c64 *scratch, int lane, int bara, const KeyBuf &kbuf, int koff, const PhaseAConsts &twu,
                                               const TwLds &twl) {
     const int c = t >= kL ? 1 : 0, p = t - c * kL;
     if (p == 0) {
@@ -544,14 +564,14 @@ __device__ __forceinline__ void fwd_step_fast(const int t, c64 (&v)[8], const c6
     }
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = {(double) decomp_digit_rt(tlo[r], p), (double) decomp_digit_rt(thi[r], p)};
-    const c64 *row = bki + (size_t) (t * 2) * kNh + lane;
+    const int row = koff + t * 2 * kNh * (int) sizeof(c64);  // byte offset of (row t, column 0) of this key sample
     brf::fwd_phaseA(v, twu);
     prio_exchange();
     t_write_A(scratch, v, lane);
     wave_sync();
     if (t > 0) {
         mac_col_f(tmpa[0], pv, kb);
-        load_col(kb, row - kNh);
+        load_col_buf(kb, kbuf, row - kNh * (int) sizeof(c64));
     }
     prio_compute();
     t_read_B(v, scratch, lane);
@@ -561,7 +581,7 @@ __device__ __forceinline__ void fwd_step_fast(const int t, c64 (&v)[8], const c6
     t_write_B(scratch, v, lane);
     wave_sync();
     if (t > 0) mac_col_f(tmpa[1], pv, kb);
-    load_col(kb, row);
+    load_col_buf(kb, kbuf, row);
     prio_compute();
     t_read_C(v, scratch, lane);
     wave_sync();
@@ -569,7 +589,7 @@ __device__ __forceinline__ void fwd_step_fast(const int t, c64 (&v)[8], const c6
 }
 
 template <bool ROTATE>
-__device__ __forceinline__ void cmux_fast(int32_t *acc, c64 *scratch, int lane, int bara, const c64 *bki,
+__device__ __forceinline__ void cmux_fast(int32_t *acc, c64 *scratch, int lane, int bara, const KeyBuf &kbuf, int koff,
                                           const PhaseAConsts &twu, const TwLds &twl) {
     c64 tmpa[2][8], kb[8], va[8], vb[8];
     uint32_t tlo[8], thi[8];
@@ -579,13 +599,13 @@ __device__ __forceinline__ void cmux_fast(int32_t *acc, c64 *scratch, int lane, 
         for (int r = 0; r < 8; r++) tmpa[c][r] = {0.0, 0.0};
 #pragma unroll 1
     for (int t = 0; t < 2 * kL; t += 2) {
-        fwd_step_fast<ROTATE>(t, va, vb, tmpa, kb, tlo, thi, acc, scratch, lane, bara, bki, twu, twl);
-        fwd_step_fast<ROTATE>(t + 1, vb, va, tmpa, kb, tlo, thi, acc, scratch, lane, bara, bki, twu, twl);
+        fwd_step_fast<ROTATE>(t, va, vb, tmpa, kb, tlo, thi, acc, scratch, lane, bara, kbuf, koff, twu, twl);
+        fwd_step_fast<ROTATE>(t + 1, vb, va, tmpa, kb, tlo, thi, acc, scratch, lane, bara, kbuf, koff, twu, twl);
     }
     // tail of the forward pipeline, then the inverse transforms A (column 0) and B (column 1)
     c64 xa[8], xb[8];
     mac_col_f(tmpa[0], vb, kb);
-    load_col(kb, bki + (size_t) (2 * kKpl - 1) * kNh + lane);
+    load_col_buf(kb, kbuf, koff + (2 * kKpl - 1) * kNh * (int) sizeof(c64));
 #pragma unroll
     for (int r = 0; r < 8; r++) xa[r] = tmpa[0][br3(r)];
     brf::inv_phaseA(xa, twu);
@@ -665,6 +685,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
     const PhaseAConsts twu = A.ka;
     const TwLds twl{tw_lds + lane};
     constexpr bool kKeySync = WAVES > 1;  // one workgroup barrier per CMux iteration (both arithmetic modes)
+    constexpr int kSampleBytes = kKpl * 2 * kNh * (int) sizeof(c64);  // one TGSW sample of the key
+    const KeyBuf kbuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<c64 *>(A.bk), 0, A.bk_bytes, 0x00020000), lane * 16};
 
     if (MODE == MODE_GATE) {
         // tfhe_bootstrap_woKS_FFT (lwe-bootstrapping-functions-fft.cpp:222-253) with the gate's linear
@@ -713,7 +735,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
             } else if (bara == 0) {
                 continue;  // lwe-bootstrapping-functions-fft.cpp:154
             }
-            if (FAST) cmux_fast<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+            if (FAST) cmux_fast<true>(acc, scratch, lane, bara, kbuf, i * kSampleBytes, twu, twl);
             else cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
         }
 #ifdef TFHE_HIP_CLOCK_DIAG
@@ -743,12 +765,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
                 const int bara = __builtin_amdgcn_readfirstlane(gbara[i]) & (2 * kN - 1);
                 if (kKeySync) __builtin_amdgcn_s_barrier();
                 else if (bara == 0) continue;
-                if (FAST) cmux_fast<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+                if (FAST) cmux_fast<true>(acc, scratch, lane, bara, kbuf, i * kSampleBytes, twu, twl);
                 else cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
             }
         } else {
             const int i = __builtin_amdgcn_readfirstlane(A.bara[g]);
-            if (FAST) cmux_fast<false>(acc, scratch, lane, 0, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+            if (FAST) cmux_fast<false>(acc, scratch, lane, 0, kbuf, i * kSampleBytes, twu, twl);
             else cmux<false>(acc, scratch, lane, 0, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
         }
 #pragma unroll
@@ -2492,6 +2514,7 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0, const c64 *custom_bk = nullptr)
         A.bk = c->bkf;
     }
     if (custom_bk) A.bk = custom_bk;  // caller-supplied TGSW operands, already in the layout of the mode
+    A.bk_bytes = custom_bk ? 0x7ffffff0 : (int) kBkBytes;  // operand indices of a caller's array are validated on the host
     const size_t lds = (fast ? brf::kFastLaneEntries : kTwLaneEntries) * sizeof(c64) + (size_t) waves * kBrLdsPerWave;
     const unsigned grid = (unsigned) ((A.B + waves - 1) / waves);
     auto go = [&](auto kernel) -> int {
