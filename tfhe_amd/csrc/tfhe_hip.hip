@@ -50,6 +50,9 @@ constexpr int kKsT = 8, kKsBasebit = 2;
 #ifndef TFHE_HIP_KO
 #define TFHE_HIP_KO 0
 #endif
+#ifndef TFHE_HIP_READS_FIRST
+#define TFHE_HIP_READS_FIRST 0  // A/B: forward steps of the FAST kernel request their transposed values before the filler MAC
+#endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct TwLds {  // this lane's column of the per-lane twiddle image in LDS (br_core.h: tw_slot_index)
     const c64 *t;  // image + lane
@@ -569,22 +572,34 @@ __device__ __forceinline__ void fwd_step_fast(const int t, c64 (&v)[8], const c6
     prio_exchange();
     t_write_A(scratch, v, lane);
     wave_sync();
+#if TFHE_HIP_READS_FIRST
+    t_read_B(v, scratch, lane);   // requested before the filler: LDS executes a wave's operations in order
+    wave_sync();
+#endif
     if (t > 0) {
         mac_col_f(tmpa[0], pv, kb);
         load_col_buf(kb, kbuf, row - kNh * (int) sizeof(c64));
     }
     prio_compute();
+#if !TFHE_HIP_READS_FIRST
     t_read_B(v, scratch, lane);
     wave_sync();
+#endif
     brf::fwd_phaseBC<brf::FS_FB>(v, twl);
     prio_exchange();
     t_write_B(scratch, v, lane);
     wave_sync();
+#if TFHE_HIP_READS_FIRST
+    t_read_C(v, scratch, lane);
+    wave_sync();
+#endif
     if (t > 0) mac_col_f(tmpa[1], pv, kb);
     load_col_buf(kb, kbuf, row);
     prio_compute();
+#if !TFHE_HIP_READS_FIRST
     t_read_C(v, scratch, lane);
     wave_sync();
+#endif
     brf::fwd_phaseBC<brf::FS_FC>(v, twl);
 }
 

@@ -5,8 +5,8 @@ set -u
 tag=$1
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
-for w in mux fft fft2048 comparator adder; do
-    timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_$w -- python3 bench.py --workload $w --steps 2 \
-        > gpurun_out/${tag}_$w.json 2> gpurun_out/${tag}_$w.err || { echo "$w failed"; exit 1; }
+for w in mux fft fft512 fft2048 "fft2048 --fft-kernel fused" comparator adder; do
+    timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_${w// /} -- python3 bench.py --workload $w --steps 2 \
+        > gpurun_out/${tag}_${w// /}.json 2> gpurun_out/${tag}_${w// /}.err || { echo "$w failed"; exit 1; }
 done
 echo "side profiles done"
