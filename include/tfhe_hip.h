@@ -105,10 +105,10 @@ const char *tfhe_hip_last_error(void);
  *          the reference's; a bootstrapped sample carries noise of the reference's distribution (same rms, unbiased)
  *          but not the reference's noise: after the first gadget digit that rounds differently the two accumulators
  *          decorrelate, as for any two FFT implementations (tests/test_fast_mode.py).  Keyswitch and all integer
- *          stages stay exact.  About 1.5x the gate throughput; a single gate in 2.2 ms instead of 3.0 ms.  Results are
- *          deterministic and independent of the position in the batch, but batches of up to 512 bootstraps run the
- *          latency kernel, which sums the 2l row products in another order than the throughput kernel: the same
- *          input bootstrapped in a small and in a large batch may differ within the tolerances above.
+ *          stages stay exact.  About 1.5x the gate throughput; a single gate in 2.1 ms instead of 3.0 ms.  Results are
+ *          deterministic and independent of the position in the batch AND of the batch size: the latency kernel (batches
+ *          of up to 512 bootstraps) accumulates the 2l row products in the throughput kernel's order, so a gate gives the
+ *          same ciphertext in a batch of 1 and of 16,384, and a netlist the same pool at every level width.
  * The call waits for the context's stream; with keys loaded it derives the FAST key (a re-indexing of the same
  * doubles, 62 MB more device memory). */
 enum { TFHE_HIP_ARITH_EXACT = 0, TFHE_HIP_ARITH_FAST = 1 };
@@ -303,6 +303,14 @@ tfhe_hip_ctx *tfhe_hip_group_ctx(tfhe_hip_group *group, int member);   /* borrow
 int tfhe_hip_group_load_keys_coef(tfhe_hip_group *group, const int32_t *bk_coef, const int32_t *ks);
 int tfhe_hip_group_load_keys_fft(tfhe_hip_group *group, const double *bkfft, const int32_t *ks);
 int tfhe_hip_group_set_arithmetic(tfhe_hip_group *group, int mode);
+/* One level of a netlist over the group (gates as for tfhe_hip_gate_level_dev; the same level contract, checked over the
+ * whole level): d_pools[member] = that member's replica of the ciphertext pool, int32[pool_rows][n+1] in ITS device memory
+ * (tfhe_hip_dev_alloc on tfhe_hip_group_ctx(group, member)), all replicas holding the same rows on entry.  The gates are
+ * split into contiguous blocks; every member evaluates its block and the rows it wrote are copied device to device into
+ * all other replicas, so that all replicas are equal again on return (and equal to a single context's pool, bit for bit).
+ * The reference has no counterpart (one device, one gate per call). */
+int tfhe_hip_group_gate_level(tfhe_hip_group *group, int32_t *const *d_pools, int64_t pool_rows, const int32_t *gates,
+                              int64_t count);
 /* how member `member` received its keys: 0 uploaded from the host (member 0), 1 device-to-device copy with peer access
  * enabled (xGMI where the GPUs are linked), 2 peer copy staged by the runtime (no peer access offered), 3 copy within one
  * device (the member shares member 0's GPU).  Replicas are verified against member 0's fingerprints before use. */

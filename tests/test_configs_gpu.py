@@ -206,3 +206,63 @@ def test_group_records_how_keys_travelled(engine, keys):
     fp = engine.key_fingerprints()
     assert len(set(fp)) == 3 and all(0 < v < 1 << 64 for v in fp)
     assert engine.key_fingerprints() == fp
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_group_netlist_levels_equal_single_context(mode, engine, fast, client, keys):
+    """tfhe_hip_group_gate_level: BASELINE configs[3] through the C-level group - every member holds a replica of the pool,
+    evaluates its block of a level and the written rows travel device to device into the other replicas.  After every
+    circuit all three replicas must equal the pool a single context computes level by level, bit for bit (EXACT and FAST:
+    FAST results do not depend on how a level is split), and a level that breaks the level contract is refused whole."""
+    from tfhe_amd import Group, TfheHipError
+    single = engine if mode == "exact" else fast
+    nbits, W = 8, 7
+    nl = Netlist()
+    x, y = nl.input("x", nbits), nl.input("y", nbits)
+    nl.output("sum", full_adder_mux(nl, x, y))
+    nl.output("le", comparison_mux(nl, x, y))
+    rng = np.random.default_rng(31)
+    xs, ys = rng.integers(0, 1 << nbits, W), rng.integers(0, 1 << nbits, W)
+    pool = np.zeros((W * nl.n_wires, P.n + 1), np.int32)
+    sh = np.arange(nbits)
+    base = (np.arange(W) * nl.n_wires)[:, None]
+    pool[(base + np.array(x)[None, :]).reshape(-1)] = client.encrypt(keys, ((xs[:, None] >> sh) & 1).reshape(-1), 1501)
+    pool[(base + np.array(y)[None, :]).reshape(-1)] = client.encrypt(keys, ((ys[:, None] >> sh) & 1).reshape(-1), 1502)
+    levels = nl.level_arrays(instances=W)
+    assert min(lv.shape[0] for lv in levels) >= 3 and len(levels) > 10
+    d_ref = single.dev_alloc(pool.nbytes)
+    g = Group([0, 0, 0])
+    members, d_pools = [], []
+    try:
+        g.load_keys_coef(keys.bk_coef, keys.ks)
+        g.set_arithmetic(mode)
+        members = [g.member(i) for i in range(3)]
+        d_pools = [m.dev_alloc(pool.nbytes) for m in members]
+        for m, d in zip(members, d_pools):
+            m.to_dev(d, pool)
+        single.to_dev(d_ref, pool)
+        for lv in levels:
+            g.gate_level(d_pools, pool.shape[0], lv)
+            single.gate_level_dev(d_ref, pool.shape[0], lv)
+        want = single.from_dev(d_ref, pool.shape)
+        for m, d in zip(members, d_pools):
+            assert np.array_equal(m.from_dev(d, pool.shape), want)
+        g.gate_level(d_pools, pool.shape[0], levels[0][:2])          # fewer gates than members: an empty block
+        g.gate_level(d_pools, pool.shape[0], levels[0][:0])
+        bad = np.array(levels[1][:4])
+        bad[3, 1] = bad[0, 2]                                         # writes a row another gate of the level reads
+        with pytest.raises(TfheHipError):
+            g.gate_level(d_pools, pool.shape[0], bad)
+        for m, d in zip(members, d_pools):                            # the refused level left every replica untouched
+            assert np.array_equal(m.from_dev(d, pool.shape), want)
+    finally:
+        for m, d in zip(members, d_pools):
+            m.dev_free(d)
+        single.dev_free(d_ref)
+        g.close()
+    outs = np.array(nl.outputs["sum"])
+    bits, _ = client.decrypt(keys, want[(base + outs[None, :]).reshape(-1)])
+    got = (bits.reshape(W, -1).astype(np.int64) << np.arange(outs.shape[0])).sum(axis=1)
+    assert np.array_equal(got, xs + ys)
+    le, _ = client.decrypt(keys, want[(base + np.array(nl.outputs["le"])[None, :]).reshape(-1)])
+    assert np.array_equal(le.reshape(-1), (xs <= ys).astype(np.uint8))

@@ -15,8 +15,13 @@ noises to stay correlated.  They do not, for ANY two transforms that differ in o
 flips (a few CMux steps in) adds a different multiple of a pseudo-random key row to the accumulator, after which the
 two masks are unrelated and every later decomposition error is an independent draw; only the modulus-switch rounding of
 the input (the same rotation amounts in both) stays common.  Measured here: noise rms 2^23.4 LSB in either mode, the
-difference of the two phases rms 2^23.6 (1.2 x the noise; sqrt 2 would be fully independent draws).  That is what
-test_bootstrap_noise_matches_the_reference asserts, together with the single-CMux closeness that does hold.
+difference of the two phases rms 2^23.6 (1.2 x the noise; sqrt 2 would be fully independent draws).
+What CARRIES the FAST contract in test_bootstrap_noise_matches_the_reference: identical bits, noise rms within 10 % of the
+reference path's, unbiased, |noise| < 2^27 - together with the single-CMux closeness (<= 4 LSB) that does hold.  The last
+assertion of that test (0.8 < rms(difference) / rms(noise) < 1.6) is DESCRIPTIVE: it records how independent the two draws
+were measured to be (1.2; the common part is the modulus-switch rounding of the input, correlation about 0.29) and would
+only fail if the two noises became identical or anti-correlated; it was first written as 1.2 < ... and widened after a run
+at 1.196 - it is not a tolerance of the arithmetic.
 """
 import os
 from concurrent.futures import ThreadPoolExecutor

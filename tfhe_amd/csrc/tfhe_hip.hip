@@ -1993,6 +1993,20 @@ __global__ __launch_bounds__(256) void k_poly_mul2048_fast(const int32_t *__rest
 // bootstrapping key of the FAST mode from the exact mode's (physical slot x holds reference bin igray(x)): the same
 // doubles, re-indexed to Z_k order [poly][k] and conjugated where the fold asks for it - no arithmetic, so the key is
 // the reference's bkFFT bit for bit in both modes
+// rows of a ciphertext pool <-> a contiguous staging buffer (tfhe_hip_group_gate_level: what a member wrote travels to the
+// other members' replicas as one peer copy)
+__global__ void k_rows_gather(int32_t *__restrict__ stage, const int32_t *__restrict__ pool, const int32_t *__restrict__ rows,
+                              long long total) {
+    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    stage[idx] = pool[(long long) rows[idx / kCt] * kCt + idx % kCt];
+}
+__global__ void k_rows_scatter(int32_t *__restrict__ pool, const int32_t *__restrict__ stage, const int32_t *__restrict__ rows,
+                               long long total) {
+    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    pool[(long long) rows[idx / kCt] * kCt + idx % kCt] = stage[idx];
+}
 // 64-bit content fingerprint of a device buffer (tfhe_hip_keys_fingerprint): sum over the 8-byte words of mix(word, index).
 // The sum is commutative, so the atomic order does not matter: equal contents give equal fingerprints on every device.
 __global__ __launch_bounds__(256) void k_fingerprint(const unsigned long long *__restrict__ p, long long words,
@@ -2404,7 +2418,7 @@ struct tfhe_hip_ctx {
     int8_t *kl = nullptr;    // [N][4][640][t][4] byte limbs (MFMA keyswitch)
     int ks_mfma = 1;
     bool have_keys = false;
-    DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc, abart, ks_part, jobs_br, jobs_ks, jobs_lin, fp;
+    DevBuf in_a, in_b, in_c, ext1, ext2, outb, misc, abart, ks_part, jobs_br, jobs_ks, jobs_lin, fp, grp_stage, grp_in, grp_rows;
     std::vector<BrJob> h_br;
     std::vector<KsJob> h_ks;
     std::vector<int32_t> h_lin;
@@ -2734,7 +2748,7 @@ void tfhe_hip_destroy(tfhe_hip_ctx *c) {
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->in_a, &c->in_b, &c->in_c, &c->ext1, &c->ext2, &c->outb, &c->misc, &c->abart, &c->ks_part, &c->jobs_br, &c->jobs_ks,
-                      &c->jobs_lin}) b->release();
+                      &c->jobs_lin, &c->fp, &c->grp_stage, &c->grp_in, &c->grp_rows}) b->release();
     if (c->tw) (void) hipFree(c->tw);
     if (c->twf) (void) hipFree(c->twf);
     if (c->cdt) (void) hipFree(c->cdt);
@@ -4031,6 +4045,64 @@ int tfhe_hip_group_gate_batch(tfhe_hip_group *g, int gate, int32_t *out, const i
         const size_t o = (size_t) lo * kCt;
         return tfhe_hip_gate_batch(g->ctx[i], gate, out + o, a ? a + o : nullptr, b ? b + o : nullptr, c ? c + o : nullptr,
                                    hi - lo);
+    });
+}
+// One level of a netlist over the group (BASELINE configs[3] on several GPUs without torch.distributed): every member
+// holds a replica of the ciphertext pool; the level's gates are split into contiguous blocks, member i evaluates its
+// block on its replica (tfhe_hip_gate_level_dev), gathers the rows it wrote into a staging buffer, and every other member
+// pulls that buffer with ONE peer copy and scatters it into its own replica - 2,524 B per gate and peer, no host copy.
+int tfhe_hip_group_gate_level(tfhe_hip_group *g, int32_t *const *d_pools, int64_t pool_rows, const int32_t *gates, int64_t count) {
+    if (!g) return fail(TFHE_HIP_ERR_ARG, "null group");
+    if (count < 0 || pool_rows < 0 || !d_pools || (count > 0 && !gates)) return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
+    const int n = (int) g->ctx.size();
+    for (int i = 0; i < n; i++)
+        if (!d_pools[i]) return fail(TFHE_HIP_ERR_ARG, "null pool replica");
+    if (count == 0) return TFHE_HIP_OK;
+    if (int r = check_ctx(g->ctx[0], true)) return r;
+    if (int r = expand_level(g->ctx[0], pool_rows, gates, count)) return r;  // the level contract over the WHOLE level
+    std::vector<int32_t> out_rows((size_t) count);
+    for (int64_t q = 0; q < count; q++) out_rows[(size_t) q] = gates[5 * q + 1];
+    // phase 1: every member evaluates its block and stages the rows it wrote
+    int rc = group_run(g, [&, n](int i) -> int {
+        tfhe_hip_ctx *c = g->ctx[i];
+        long long lo, hi;
+        shard(count, i, n, lo, hi);
+        if (int r = check_ctx(c, true)) return r;
+        HIPCHK(c->grp_rows.reserve((size_t) count * sizeof(int32_t)));
+        HIPCHK(hipMemcpyAsync(c->grp_rows.p, out_rows.data(), (size_t) count * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        if (hi == lo) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            return TFHE_HIP_OK;
+        }
+        if (int r = tfhe_hip_gate_level_dev(c, d_pools[i], pool_rows, gates + 5 * lo, hi - lo)) return r;
+        if (n == 1) return TFHE_HIP_OK;
+        const long long total = (hi - lo) * kCt;
+        HIPCHK(c->grp_stage.reserve((size_t) total * sizeof(int32_t)));
+        hipLaunchKernelGGL(k_rows_gather, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream, (int32_t *) c->grp_stage.p,
+                           (const int32_t *) d_pools[i], (const int32_t *) c->grp_rows.p + lo, total);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return TFHE_HIP_OK;
+    });
+    if (rc || n == 1) return rc;
+    // phase 2: every member pulls the other members' staged rows into its own replica
+    return group_run(g, [&, n](int j) -> int {
+        tfhe_hip_ctx *c = g->ctx[j];
+        HIPCHK(hipSetDevice(c->device));
+        for (int i = 0; i < n; i++) {
+            long long lo, hi;
+            shard(count, i, n, lo, hi);
+            if (i == j || hi == lo) continue;
+            const long long total = (hi - lo) * kCt;
+            HIPCHK(c->grp_in.reserve((size_t) total * sizeof(int32_t)));
+            HIPCHK(hipMemcpyPeerAsync(c->grp_in.p, c->device, g->ctx[i]->grp_stage.p, g->ctx[i]->device, (size_t) total * sizeof(int32_t),
+                                      c->stream));
+            hipLaunchKernelGGL(k_rows_scatter, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, c->stream, d_pools[j],
+                               (const int32_t *) c->grp_in.p, (const int32_t *) c->grp_rows.p + lo, total);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c->stream));  // grp_in is reused by the next peer
+        }
+        return TFHE_HIP_OK;
     });
 }
 }  // extern "C"

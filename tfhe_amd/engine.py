@@ -70,6 +70,7 @@ EXPORTS = [
     "tfhe_hip_group_create", "tfhe_hip_group_destroy", "tfhe_hip_group_size", "tfhe_hip_group_ctx",
     "tfhe_hip_group_load_keys_coef", "tfhe_hip_group_load_keys_fft", "tfhe_hip_group_set_arithmetic",
     "tfhe_hip_group_gate_batch", "tfhe_hip_group_key_path", "tfhe_hip_keys_fingerprint",
+    "tfhe_hip_group_gate_level",
     "tfhe_hip_tgsw_fft_extern_mul_batch", "tfhe_hip_tgsw_extern_mul_batch", "tfhe_hip_tlwe_addmul_r_batch",
     "tfhe_hip_negacyclic_mul_n_batch", "tfhe_hip_negacyclic_mul_n_batch_dev", "tfhe_hip_int_ifft_n_batch",
     "tfhe_hip_torus_ifft_n_batch", "tfhe_hip_torus_fft_n_batch", "tfhe_hip_tgsw_decomp_n_batch",
@@ -186,6 +187,22 @@ class Group:
     def set_arithmetic(self, mode):
         code = {"exact": 0, "fast": 1}[mode] if isinstance(mode, str) else int(mode)
         self._chk(self.lib.tfhe_hip_group_set_arithmetic(self.handle, code), "group_set_arithmetic")
+
+    def member(self, i):
+        """borrowed Engine view of member i's context (device-memory helpers, *_dev entry points); do not close it"""
+        self.lib.tfhe_hip_group_ctx.restype = ctypes.c_void_p
+        e = Engine.__new__(Engine)
+        e.params, e.lib, e.device = self.params, self.lib, None
+        e.ctx = ctypes.c_void_p(self.lib.tfhe_hip_group_ctx(self.handle, i))
+        e.close = lambda: None
+        return e
+
+    def gate_level(self, pools, pool_rows, gates):
+        """tfhe_hip_group_gate_level: pools = one device pointer per member (replicas of the ciphertext pool)"""
+        g = np.ascontiguousarray(gates, dtype=np.int32).reshape(-1, 5)
+        arr = (ctypes.c_void_p * len(pools))(*[ctypes.c_void_p(p) for p in pools])
+        self._chk(self.lib.tfhe_hip_group_gate_level(self.handle, arr, ctypes.c_int64(pool_rows), _p(g),
+                                                     ctypes.c_int64(g.shape[0])), "group_gate_level")
 
     def key_paths(self):
         """per member: 0 host upload, 1 peer copy with peer access, 2 peer copy staged by the runtime, 3 same device"""
