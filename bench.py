@@ -382,6 +382,8 @@ def main():
                     help="gates per GPU per step; default 16384 on one GPU (BASELINE configs[1]) and 2^20 / 8 = 131072 on "
                          "several (on 8 GPUs the job is BASELINE configs[2]: 2^20 gates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-inclusive", action="store_true",
+                    help="skip the host-buffer leg (profiling runs: its chunked launches would blur the per-kernel averages)")
     ap.add_argument("--workload", default="nand", choices=["nand", "mux", "fft", "fft2048", "fft512", "adder", "comparator"],
                     help="nand: BASELINE configs[1] (default, the headline); adder / comparator: configs[3] levelized "
                          "32-bit circuits; mux / fft / fft2048: configs[4] side benches")
@@ -534,7 +536,7 @@ def main():
     # the same batch from and to HOST arrays (tfhe_hip_gate_batch: chunked copies overlapped with the kernels), outside
     # the headline's timed region: SURVEY 8(d) states the metric host to host; `value` stays the HBM-resident rate
     host_inc = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_host_inclusive:
         def host_rate(a_, b_):
             eng.gate_batch(Gate.NAND, a_, b_)
             t1 = time.perf_counter()

@@ -201,7 +201,7 @@ struct BrArgs {
     int32_t *acc_io;       // MODE_RAW / MODE_EXTMUL: TLWE accumulators [B][2][N], in/out
     const int32_t *bara;   // MODE_RAW: [B][n] rotation amounts; MODE_EXTMUL: [B] key index
     const c64 *bk;         // [n][6][2][8][64] physical slot order
-    int bk_bytes;          // size of the key array behind bk (buffer-resource bound of the FAST kernel's key loads)
+    int bk_bytes;          // size of the key array behind bk (buffer-resource bound of the throughput kernels' key loads)
     const c64 *tw;         // per-lane twiddle image, kTwLaneEntries
     PhaseAConsts ka;       // in-register-phase twiddles (scalar registers)
     long long B;
@@ -229,17 +229,8 @@ __device__ __forceinline__ void mac_col(c64 (&acc)[8], const c64 (&v)[8], const 
 #pragma unroll
     for (int r = 0; r < 8; r++) cmac(acc[r], v[r], kb[r]);
 }
-__device__ __forceinline__ void load_col(c64 (&kb)[8], const c64 *row) {
-#if TFHE_HIP_KO & 4
-#pragma unroll
-    for (int r = 0; r < 8; r++) kb[r] = c64{0.25 + r, 0.5 - (double) ((size_t) row & 1)};
-#else
-#pragma unroll
-    for (int r = 0; r < 8; r++) kb[r] = row[r * 64];
-#endif
-}
-// the same through a buffer resource: address = base (descriptor) + lane offset (one VGPR, set once) + uniform offset of
-// the column and r KB (an SGPR, computed on the scalar unit), instead of a 64-bit address per lane and load
+// key column (8 values per lane) through a buffer resource: address = base (descriptor) + lane offset (one VGPR, set once) +
+// uniform offset of the column and r KB (an SGPR, computed on the scalar unit), instead of a 64-bit address per lane and load
 struct KeyBuf {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff;  // lane * 16
@@ -307,7 +298,7 @@ __device__ __forceinline__ void prio_exchange() { __builtin_amdgcn_s_setprio(0);
 template <bool ROTATE>
 __device__ __forceinline__ void fwd_step(const int t, c64 (&v)[8], const c64 (&pv)[8], c64 (&tmpa)[2][8],
                                          c64 (&kb)[8], uint32_t (&tlo)[8], uint32_t (&thi)[8], const int32_t *acc,
-                                         c64 *scratch, int lane, int bara, const c64 *bki, const PhaseAConsts &twu,
+                                         c64 *scratch, int lane, int bara, const KeyBuf &kbuf, int koff, const PhaseAConsts &twu,
                                          const TwLds &twl) {
     const int c = t >= kL ? 1 : 0, p = t - c * kL;
     if (p == 0) {  // rotated differences of column c, offset added and digit sign bits flipped (decomp_prepare)
@@ -328,7 +319,7 @@ __device__ __forceinline__ void fwd_step(const int t, c64 (&v)[8], const c64 (&p
     for (int r = 0; r < 8; r++) v[r] = {(double) decomp_digit_rt(tlo[r], p), (double) decomp_digit_rt(thi[r], p)};
     // one 8-value key buffer in rotation: holds (row t-1, column 0) on entry, (row t-1, column 1) between the two
     // gaps, (row t, column 0) on exit
-    const c64 *row = bki + (size_t) (t * 2) * kNh + lane;
+    const int row = koff + t * 2 * kNh * (int) sizeof(c64);  // byte offset of (row t, column 0), uniform
     fwd_phaseA(v, twu);
     prio_exchange();
 #pragma unroll
@@ -336,7 +327,7 @@ __device__ __forceinline__ void fwd_step(const int t, c64 (&v)[8], const c64 (&p
     wave_sync();
     if (t > 0) {
         mac_col(tmpa[0], pv, kb);
-        load_col(kb, row - kNh);
+        load_col_buf(kb, kbuf, row - kNh * (int) sizeof(c64));
     }
     prio_compute();
 #pragma unroll
@@ -348,7 +339,7 @@ __device__ __forceinline__ void fwd_step(const int t, c64 (&v)[8], const c64 (&p
     for (int r = 0; r < 8; r++) scratch[swz(fwd_xB(lane, r))] = v[r];
     wave_sync();
     if (t > 0) mac_col(tmpa[1], pv, kb);
-    load_col(kb, row);
+    load_col_buf(kb, kbuf, row);
     prio_compute();
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = scratch[swz(fwd_xC(lane, r))];
@@ -357,7 +348,7 @@ __device__ __forceinline__ void fwd_step(const int t, c64 (&v)[8], const c64 (&p
 }
 
 template <bool ROTATE>
-__device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int bara, const c64 *bki,
+__device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int bara, const KeyBuf &kbuf, int koff,
                                      const PhaseAConsts &twu, const TwLds &twl) {
     c64 tmpa[2][8], kb[8], va[8], vb[8];
     uint32_t tlo[8], thi[8];
@@ -367,13 +358,13 @@ __device__ __forceinline__ void cmux(int32_t *acc, c64 *scratch, int lane, int b
         for (int r = 0; r < 8; r++) tmpa[c][r] = {0.0, 0.0};
 #pragma unroll 1
     for (int t = 0; t < 2 * kL; t += 2) {
-        fwd_step<ROTATE>(t, va, vb, tmpa, kb, tlo, thi, acc, scratch, lane, bara, bki, twu, twl);
-        fwd_step<ROTATE>(t + 1, vb, va, tmpa, kb, tlo, thi, acc, scratch, lane, bara, bki, twu, twl);
+        fwd_step<ROTATE>(t, va, vb, tmpa, kb, tlo, thi, acc, scratch, lane, bara, kbuf, koff, twu, twl);
+        fwd_step<ROTATE>(t + 1, vb, va, tmpa, kb, tlo, thi, acc, scratch, lane, bara, kbuf, koff, twu, twl);
     }
     // tail of the forward pipeline and the two inverse transforms A (column 0) and B (column 1), staggered
     c64 xa[16], xb[16], wa[16], wb[16];
     mac_col(tmpa[0], vb, kb);
-    load_col(kb, bki + (size_t) (2 * kKpl - 1) * kNh + lane);
+    load_col_buf(kb, kbuf, koff + (2 * kKpl - 1) * kNh * (int) sizeof(c64));
     prio_exchange();
     spec_write(scratch, tmpa[0], lane);
     wave_sync();
@@ -751,7 +742,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
                 continue;  // lwe-bootstrapping-functions-fft.cpp:154
             }
             if (FAST) cmux_fast<true>(acc, scratch, lane, bara, kbuf, i * kSampleBytes, twu, twl);
-            else cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+            else cmux<true>(acc, scratch, lane, bara, kbuf, i * kSampleBytes, twu, twl);
         }
 #ifdef TFHE_HIP_CLOCK_DIAG
         if (A.diag && lane == 0) {
@@ -781,12 +772,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
                 if (kKeySync) __builtin_amdgcn_s_barrier();
                 else if (bara == 0) continue;
                 if (FAST) cmux_fast<true>(acc, scratch, lane, bara, kbuf, i * kSampleBytes, twu, twl);
-                else cmux<true>(acc, scratch, lane, bara, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+                else cmux<true>(acc, scratch, lane, bara, kbuf, i * kSampleBytes, twu, twl);
             }
         } else {
             const int i = __builtin_amdgcn_readfirstlane(A.bara[g]);
             if (FAST) cmux_fast<false>(acc, scratch, lane, 0, kbuf, i * kSampleBytes, twu, twl);
-            else cmux<false>(acc, scratch, lane, 0, A.bk + (size_t) i * kKpl * 2 * kNh, twu, twl);
+            else cmux<false>(acc, scratch, lane, 0, kbuf, i * kSampleBytes, twu, twl);
         }
 #pragma unroll
         for (int q = 0; q < 32; q++) io[q * 64 + lane] = acc[q * 64 + lane];

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
 run() {  # name, rocprofv3 options...
     local name=$1; shift
-    timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d gpurun_out/${tag}_${name} -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 $BENCH_ARGS \
+    timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d gpurun_out/${tag}_${name} -- python3 bench.py --no-cpu-baseline --no-host-inclusive --steps 1 --warmup 0 $BENCH_ARGS \
         > gpurun_out/${tag}_${name}.out 2> gpurun_out/${tag}_${name}.err || { echo "pass $name failed"; exit 1; }
 }
 BENCH_ARGS="$*"
@@ -18,6 +18,6 @@ run tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 BENCH_ARGS="$* --steps 5 --warmup 1"
-timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 bench.py --no-cpu-baseline $BENCH_ARGS \
+timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 bench.py --no-cpu-baseline --no-host-inclusive $BENCH_ARGS \
     > gpurun_out/${tag}_stats.out 2> gpurun_out/${tag}_stats.err || { echo "stats pass failed"; exit 1; }
 echo "passes done"
