@@ -73,6 +73,14 @@ def test_gpu_batch_equals_the_oracle_and_fast_mode_is_close(engine, oracle, keys
     assert np.abs(wrap(out_c.astype(np.int64) - out_f)).max() <= P.kpl
     with pytest.raises(TfheHipError):
         engine.tgsw_extern_mul(acc[:1], tgsw, np.array([ngsw], np.int32))
+    # operand arrays are addressed with 32-bit byte offsets: more than 2 GiB of samples in one call is refused before
+    # anything is read (the arrays passed here are far smaller than the count claims)
+    import ctypes
+    one = acc[:1].copy()
+    rc = engine.lib.tfhe_hip_tgsw_fft_extern_mul_batch(engine.ctx, one.ctypes.data_as(ctypes.c_void_p),
+                                                       gfft.ctypes.data_as(ctypes.c_void_p), idx[:1].ctypes.data_as(ctypes.c_void_p),
+                                                       ctypes.c_int64(30000), ctypes.c_int64(1))
+    assert rc != 0 and b"2 GiB" in engine.lib.tfhe_hip_last_error()
     e = Engine(0)
     try:
         e.set_arithmetic("fast")               # no keys needed for these stages

@@ -3536,6 +3536,9 @@ int tfhe_hip_tgsw_fft_extern_mul_batch(tfhe_hip_ctx *c, int32_t *acc, const doub
         return fail(TFHE_HIP_ERR_ARG, "bad buffer or count");
     if (count == 0) return TFHE_HIP_OK;
     if (int r = check_index(gsw_index, count, ngsw)) return r;
+    // the kernel addresses the operand array through a buffer resource with 32-bit byte offsets
+    if ((unsigned long long) ngsw * kKpl * 2 * kNh * sizeof(c64) > 0x7ffffff0ull)
+        return fail(TFHE_HIP_ERR_ARG, "more than 2 GiB of TGSW operands in one call: split it");
     const size_t op_bytes = (size_t) ngsw * kKpl * 2 * kNh * sizeof(c64), ab = (size_t) count * 2 * kN * sizeof(int32_t);
     const long long total = (long long) ngsw * kKpl * 2 * kNh;
     const bool fast = c->arith == TFHE_HIP_ARITH_FAST;
