@@ -231,6 +231,22 @@ __device__ __forceinline__ void mac_col(c64 (&acc)[8], const c64 (&v)[8], const 
 }
 // key column (8 values per lane) through a buffer resource: address = base (descriptor) + lane offset (one VGPR, set once) +
 // uniform offset of the column and r KB (an SGPR, computed on the scalar unit), instead of a 64-bit address per lane and load
+#ifndef TFHE_HIP_SKEW
+#define TFHE_HIP_SKEW 0  // A/B: 1 = skewed forward pipeline of the FAST throughput kernel (fwd_body_skew; measured 1.6 % slower)
+#endif
+#ifndef TFHE_HIP_SKEW_PRIO
+#define TFHE_HIP_SKEW_PRIO 0  // A/B: static wave priorities around the exchanges of the skewed pipeline
+#endif
+#if TFHE_HIP_SKEW_PRIO
+#define SKEW_PRIO_EXCHANGE() prio_exchange()
+#define SKEW_PRIO_COMPUTE() prio_compute()
+#else
+#define SKEW_PRIO_EXCHANGE() ((void) 0)
+#define SKEW_PRIO_COMPUTE() ((void) 0)
+#endif
+#ifndef TFHE_HIP_BARRIER_EVERY
+#define TFHE_HIP_BARRIER_EVERY 1  // A/B: the waves of a workgroup meet every 1 | 2 | 4 CMux iterations (power of two)
+#endif
 struct KeyBuf {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff;  // lane * 16
@@ -594,6 +610,76 @@ __device__ __forceinline__ void fwd_step_fast(const int t, c64 (&v)[8], const c6
     brf::fwd_phaseBC<brf::FS_FC>(v, twl);
 }
 
+// Skewed forward pipeline (TFHE_HIP_SKEW=1, round 3; A/B switch, off: measured 75.9-76.0 against 74.7 ms per 16,384 gates on the
+// same box, 75.4 with static priorities - twice the cover per exchange does not help, i.e. the waves are not waiting for their
+// own exchanges but for the shared LDS and VALU).  In fwd_step_fast every exchange of transform t is covered by ONE MAC
+// of transform t-1 (64 FMA).  Here the last phase of transform t-1 is postponed behind the first phase of transform t, so
+// that each exchange is covered by a butterfly phase AND a MAC of the neighbouring transform:
+//   body(t) = [M1(t-2)] [digits_t, A_t] [read2(t-1)] [write1(t)] [C_(t-1), M0(t-1)] [read1(t), B_t] [write2(t)]
+//   exchange 1 of t (write1 -> read1): C_(t-1) + M0(t-1);  exchange 2 of t (write2 -> read2 in body(t+1)): M1(t-1) + digits + A_(t+1).
+// One scratch suffices: read2(t-1) is ISSUED before write1(t) and LDS executes a wave's operations in issue order.  Same
+// registers (two value buffers, one rotating key buffer), same arithmetic in the same order per accumulator: results are
+// bit-identical to fwd_step_fast's.  X = buffer of transform t, Y = buffer of transform t-1.
+template <bool ROTATE>
+__device__ __forceinline__ void fwd_digits_fast(const int t, c64 (&v)[8], uint32_t (&tlo)[8], uint32_t (&thi)[8], const int32_t *acc,
+                                                int lane, int bara) {
+    const int c = t >= kL ? 1 : 0, p = t - c * kL;
+    if (p == 0) {
+        const int32_t *accc = acc + c * kN;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int j = (br3(r) << 6) | lane;
+#if TFHE_HIP_KO & 8
+            tlo[r] = decomp_prepare(j * bara + c);
+            thi[r] = decomp_prepare(j - bara);
+            continue;
+#endif
+            if (ROTATE) {
+                tlo[r] = decomp_prepare(rot_minus_one(accc, bara, j));
+                thi[r] = decomp_prepare(rot_minus_one(accc, bara, j + kNh));
+            } else {
+                tlo[r] = decomp_prepare(accc[j]);
+                thi[r] = decomp_prepare(accc[j + kNh]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = {(double) decomp_digit_rt(tlo[r], p), (double) decomp_digit_rt(thi[r], p)};
+}
+template <bool ROTATE>
+__device__ __forceinline__ void fwd_body_skew(const int t, c64 (&X)[8], c64 (&Y)[8], c64 (&tmpa)[2][8], c64 (&kb)[8],
+                                              uint32_t (&tlo)[8], uint32_t (&thi)[8], const int32_t *acc, c64 *scratch, int lane,
+                                              int bara, const KeyBuf &kbuf, int koff, const PhaseAConsts &twu, const TwLds &twl) {
+    constexpr int kColBytes = kNh * (int) sizeof(c64);
+    const int row = koff + t * 2 * kColBytes;  // byte offset of (row t, column 0) of this key sample
+    if (t >= 2) mac_col_f(tmpa[1], X, kb);                      // M1(t-2): X still holds the spectrum of transform t-2
+    if (t >= 1) load_col_buf(kb, kbuf, row - 2 * kColBytes);    // key (t-1, column 0)
+    fwd_digits_fast<ROTATE>(t, X, tlo, thi, acc, lane, bara);
+    brf::fwd_phaseA(X, twu);
+    TwPre<4> twc;
+    if (t >= 1) {
+        t_read_C(Y, scratch, lane);                             // read2(t-1), issued ahead of write1(t)
+        tw_preload(twc, twl, brf::FS_FC);                       // ... and so are the twiddles of C_(t-1)
+        wave_sync();
+    }
+    SKEW_PRIO_EXCHANGE();
+    t_write_A(scratch, X, lane);
+    wave_sync();
+    SKEW_PRIO_COMPUTE();
+    if (t >= 1) {
+        brf::fwd_phaseBC<brf::FS_FC>(Y, TwView<4, brf::FS_FC>{twc});
+        mac_col_f(tmpa[0], Y, kb);                              // M0(t-1)
+        load_col_buf(kb, kbuf, row - kColBytes);                // key (t-1, column 1)
+    }
+    t_read_B(X, scratch, lane);
+    wave_sync();
+    brf::fwd_phaseBC<brf::FS_FB>(X, twl);
+    SKEW_PRIO_EXCHANGE();
+    t_write_B(scratch, X, lane);
+    wave_sync();
+    SKEW_PRIO_COMPUTE();
+}
+
 template <bool ROTATE>
 __device__ __forceinline__ void cmux_fast(int32_t *acc, c64 *scratch, int lane, int bara, const KeyBuf &kbuf, int koff,
                                           const PhaseAConsts &twu, const TwLds &twl) {
@@ -603,11 +689,25 @@ __device__ __forceinline__ void cmux_fast(int32_t *acc, c64 *scratch, int lane, 
     for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int r = 0; r < 8; r++) tmpa[c][r] = {0.0, 0.0};
+#if TFHE_HIP_SKEW
+#pragma unroll 1
+    for (int t = 0; t < 2 * kL; t += 2) {
+        fwd_body_skew<ROTATE>(t, va, vb, tmpa, kb, tlo, thi, acc, scratch, lane, bara, kbuf, koff, twu, twl);
+        fwd_body_skew<ROTATE>(t + 1, vb, va, tmpa, kb, tlo, thi, acc, scratch, lane, bara, kbuf, koff, twu, twl);
+    }
+    // drain: M1(2l-2), then the last phase of transform 2l-1 (vb), whose MACs open the tail below
+    mac_col_f(tmpa[1], va, kb);
+    load_col_buf(kb, kbuf, koff + (2 * kKpl - 2) * kNh * (int) sizeof(c64));
+    t_read_C(vb, scratch, lane);
+    wave_sync();
+    brf::fwd_phaseBC<brf::FS_FC>(vb, twl);
+#else
 #pragma unroll 1
     for (int t = 0; t < 2 * kL; t += 2) {
         fwd_step_fast<ROTATE>(t, va, vb, tmpa, kb, tlo, thi, acc, scratch, lane, bara, kbuf, koff, twu, twl);
         fwd_step_fast<ROTATE>(t + 1, vb, va, tmpa, kb, tlo, thi, acc, scratch, lane, bara, kbuf, koff, twu, twl);
     }
+#endif
     // tail of the forward pipeline, then the inverse transforms A (column 0) and B (column 1)
     c64 xa[8], xb[8];
     mac_col_f(tmpa[0], vb, kb);
@@ -737,7 +837,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
                 // and adds exactly nothing in either arithmetic mode (the exact-mode parity tests cover such iterations), as in the
                 // reference's device loop (src/kernels/tfhe_blindRotate_FFT.cpp:18-28).  Measured: 122.0 -> 118.4 ms (exact), 80.7 -> 76.9 ms (fast).
                 // Waves that have ended (ragged last workgroup) are left out of the barrier by the hardware.
-                __builtin_amdgcn_s_barrier();
+                if ((i & (TFHE_HIP_BARRIER_EVERY - 1)) == 0) __builtin_amdgcn_s_barrier();
             } else if (bara == 0) {
                 continue;  // lwe-bootstrapping-functions-fft.cpp:154
             }
