@@ -432,11 +432,14 @@ def main():
     torch.cuda.set_device(dev_index)            # torch first, then the engine: both then share one HIP runtime
     dev = torch.device("cuda", dev_index)
     if world > 1:
-        backend = os.environ.get("TFHE_BENCH_BACKEND", "nccl")   # "gloo" only for the 1-GPU rehearsal
+        # RCCL needs a device per rank: with more ranks than devices (the rehearsal on a 1-GPU box) fall back to gloo
+        backend = os.environ.get("TFHE_BENCH_BACKEND", "nccl" if world <= max(ndev, 1) else "gloo")
+        import datetime
+        limit = datetime.timedelta(minutes=10)                    # a collective that never completes ends the run, not hangs it
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     if args.workload != "nand":
         return side_bench(args, torch, dev, rank, world)
