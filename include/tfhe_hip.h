@@ -308,6 +308,8 @@ int tfhe_hip_group_set_arithmetic(tfhe_hip_group *group, int mode);
  * (tfhe_hip_dev_alloc on tfhe_hip_group_ctx(group, member)), all replicas holding the same rows on entry.  The gates are
  * split into contiguous blocks; every member evaluates its block and the rows it wrote are copied device to device into
  * all other replicas, so that all replicas are equal again on return (and equal to a single context's pool, bit for bit).
+ * A level that violates the contract is refused before any member runs; after a run-time error (a HIP failure on one
+ * member) the replicas may differ: restore them from one that the caller trusts.
  * The reference has no counterpart (one device, one gate per call). */
 int tfhe_hip_group_gate_level(tfhe_hip_group *group, int32_t *const *d_pools, int64_t pool_rows, const int32_t *gates,
                               int64_t count);
