@@ -244,6 +244,9 @@ __device__ __forceinline__ void mac_col(c64 (&acc)[8], const c64 (&v)[8], const 
 #define SKEW_PRIO_EXCHANGE() ((void) 0)
 #define SKEW_PRIO_COMPUTE() ((void) 0)
 #endif
+#ifndef TFHE_HIP_BARA_AHEAD
+#define TFHE_HIP_BARA_AHEAD 1  // A/B: gate kernels request the input coefficients of iteration i + 1 during iteration i
+#endif
 #ifndef TFHE_HIP_BARRIER_EVERY
 #define TFHE_HIP_BARRIER_EVERY 1  // A/B: the waves of a workgroup meet every 1 | 2 | 4 CMux iterations (power of two)
 #endif
@@ -826,9 +829,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
 #ifdef TFHE_HIP_CLOCK_DIAG
         const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+        // The two input coefficients of iteration i + 1 are requested at the top of iteration i and used at the top of the
+        // next one: otherwise two dependent global loads sit on the critical path of every iteration, with all waves of
+        // the workgroup - just synchronised by the barrier - waiting for them at the same time (index n = the b
+        // coefficient: always in range)
+#if TFHE_HIP_BARA_AHEAD
+        int32_t ra = ga[0], rb = gb ? gb[0] : 0;
+#endif
 #pragma unroll 1
         for (int i = 0; i < kLwe; i++) {
+#if TFHE_HIP_BARA_AHEAD
+            const uint32_t lin = (uint32_t) sa * (uint32_t) ra + (gb ? (uint32_t) sb * (uint32_t) rb : 0u);
+            const int bara = __builtin_amdgcn_readfirstlane(modswitch_2N((int32_t) lin));
+            ra = ga[i + 1];
+            if (gb) rb = gb[i + 1];
+#else
             const int bara = __builtin_amdgcn_readfirstlane(modswitch_2N(comb(i)));
+#endif
             if (kKeySync) {
                 // All waves of the workgroup enter iteration i together: the 96 KB of bk_i that every wave streams then
                 // come out of the CU's vector cache for all but the first of them instead of once per wave out of L2
