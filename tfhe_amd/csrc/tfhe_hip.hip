@@ -883,9 +883,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_blind_rotate(BrArgs A) {
         if (MODE == MODE_RAW) {
             // tfhe_blindRotate_FFT (the reference's device seam), CPU loop at :146-164
             const int32_t *gbara = A.bara + g * kLwe;
+            int32_t rn = gbara[0];  // requested one iteration ahead, as in the gate loop
 #pragma unroll 1
             for (int i = 0; i < kLwe; i++) {
-                const int bara = __builtin_amdgcn_readfirstlane(gbara[i]) & (2 * kN - 1);
+                const int bara = __builtin_amdgcn_readfirstlane(rn) & (2 * kN - 1);
+                rn = gbara[i + 1 < kLwe ? i + 1 : i];
                 if (kKeySync) __builtin_amdgcn_s_barrier();
                 else if (bara == 0) continue;
                 if (FAST) cmux_fast<true>(acc, scratch, lane, bara, kbuf, i * kSampleBytes, twu, twl);
