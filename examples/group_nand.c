@@ -1,5 +1,6 @@
 /* A batch of NAND gates over a device group, in plain C: one context, stream and host thread per listed GPU, keys
- * uploaded once and replicated device to device, the batch split into contiguous shards.
+ * uploaded once and replicated device to device, the batch split into contiguous shards; then a two-level netlist over
+ * replicated ciphertext pools (tfhe_hip_group_gate_level).
  *   gcc -O2 -Iinclude examples/group_nand.c -Ltfhe_amd -ltfhe_hip -ltfhe_client -Wl,-rpath,$PWD/tfhe_amd -o group_nand
  *   ./group_nand 20000 0 1 2 3        (gate count, then the devices; a device may be listed twice)
  * The reference has no multi-device code; its equivalent is the loop of src/test/test-gate-bootstrapping.cpp:60-80. */
@@ -50,6 +51,41 @@ int main(int argc, char **argv) {
     const int same = memcmp(co, single, bytes) == 0;
     printf("%lld NAND gates on %d member(s), %lld wrong, group == single context: %s\n", (long long) count,
            tfhe_hip_group_size(grp), (long long) bad, same ? "yes" : "NO");
+
+    /* a two-level netlist over the group: rows [0, m) = a, [m, 2m) = b, level 1: x = a NAND b into [2m, 3m), level 2:
+     * y = x XOR a into [3m, 4m).  Every member holds a replica of the pool; each evaluates its block of a level and the
+     * rows it wrote travel device to device into the other replicas. */
+    const int64_t m = count < 600 ? count : 600, rows = 4 * m;
+    const size_t pool_bytes = (size_t) rows * (n + 1) * 4, part = (size_t) m * (n + 1) * 4;
+    int32_t *pool = calloc(1, pool_bytes), *back = malloc(pool_bytes), *gates = malloc((size_t) m * 5 * 4);
+    memcpy(pool, ca, part);
+    memcpy((char *) pool + part, cb, part);
+    int32_t *replica[64];
+    for (int d = 0; d < ndev; d++) {
+        CHECK(tfhe_hip_dev_alloc(tfhe_hip_group_ctx(grp, d), pool_bytes, (void **) &replica[d]));
+        CHECK(tfhe_hip_copy_to_dev(tfhe_hip_group_ctx(grp, d), replica[d], pool, pool_bytes));
+    }
+    for (int level = 0; level < 2; level++) {
+        for (int64_t i = 0; i < m; i++) {
+            int32_t *g = gates + 5 * i;
+            g[0] = level == 0 ? TFHE_HIP_NAND : TFHE_HIP_XOR;
+            g[1] = (int32_t) ((2 + level) * m + i);
+            g[2] = (int32_t) (level == 0 ? i : 2 * m + i);
+            g[3] = (int32_t) (level == 0 ? m + i : i);
+            g[4] = -1;
+        }
+        CHECK(tfhe_hip_group_gate_level(grp, replica, rows, gates, m));
+    }
+    int64_t bad2 = 0, differ = 0;
+    for (int d = 0; d < ndev; d++) {
+        CHECK(tfhe_hip_copy_from_dev(tfhe_hip_group_ctx(grp, d), d == 0 ? pool : back, replica[d], pool_bytes));
+        if (d > 0) differ += memcmp(pool, back, pool_bytes) != 0;
+        CHECK(tfhe_hip_dev_free(tfhe_hip_group_ctx(grp, d), replica[d]));
+    }
+    tfhe_client_decrypt(lwe_key, n, pool + 3 * m * (n + 1), m, got, NULL);
+    for (int64_t i = 0; i < m; i++) bad2 += got[i] != (uint8_t) ((1 - (a[i] & b[i])) ^ a[i]);
+    printf("%lld two-level circuits over the group, %lld wrong, replicas equal: %s\n", (long long) m, (long long) bad2,
+           differ ? "NO" : "yes");
     tfhe_hip_group_destroy(grp);
-    return bad != 0 || !same;
+    return bad != 0 || !same || bad2 != 0 || differ != 0;
 }

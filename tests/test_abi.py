@@ -94,3 +94,4 @@ def test_group_c_example_runs(tmp_path):
     out = subprocess.run([_build_example(tmp_path, "group_nand"), "5001", "0", "0"], check=True, capture_output=True,
                          text=True, timeout=180).stdout
     assert "5001 NAND gates on 2 member(s), 0 wrong, group == single context: yes" in out
+    assert "600 two-level circuits over the group, 0 wrong, replicas equal: yes" in out

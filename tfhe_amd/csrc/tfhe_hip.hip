@@ -1188,7 +1188,9 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
 //      (B of waves 1 and 2: the sums of column 0 / 1; A and B of wave 0: the inverse waves' scratch), 8 KB each
 //      | rotation list | prepared differences 8 KB
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kCoopFastWaves = kKpl + 2;  // 2l forward waves, one inverse wave per accumulator column
+// 2l forward waves, one inverse wave per accumulator column, and - where that leaves fewer than eight (the 80-bit set:
+// 2l = 4) - helper waves that only take part in the product phase, so that its 16 units split evenly (two per wave)
+constexpr int kCoopFastWaves = kKpl + 2 < 8 ? 8 : kKpl + 2;
 constexpr int kCoopFastLds = brf::kFastLaneEntries * (int) sizeof(c64) + 2 * kN * 4 + kKpl * 2 * kNh * (int) sizeof(c64) +
                              2 * 640 * 4 + 2 * kN * 4;
 static_assert(kCoopFastLds <= 160 * 1024, "LDS of one CU");
@@ -1208,8 +1210,8 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
     unsigned char *ptr = lds_raw + brf::kFastLaneEntries * sizeof(c64);
     int32_t *acc = reinterpret_cast<int32_t *>(ptr);
     c64 *bufs = reinterpret_cast<c64 *>(ptr + 2 * kN * 4);
-    const bool fwd_role = wave < kKpl;
-    const int ic = wave - kKpl;  // inverse role: accumulator column
+    const bool fwd_role = wave < kKpl, inv_role = wave >= kKpl && wave < kKpl + 2;
+    const int ic = inv_role ? wave - kKpl : 0;  // inverse role: accumulator column
     c64 *mineA = bufs + (size_t) (fwd_role ? wave : 0) * 2 * kNh, *mineB = mineA + kNh;
     int32_t *bara_lds = reinterpret_cast<int32_t *>(bufs + (size_t) kKpl * 2 * kNh);
     int32_t *act = bara_lds + 640;                                   // (index << 16 | amount) of the non-zero rotations; [639] = count
@@ -1270,7 +1272,7 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
     __syncthreads();
     const int nact = __builtin_amdgcn_readfirstlane(act[639]);
     int32_t own_lo[8], own_hi[8];  // inverse waves: coefficients j = r<<6|lane and j + 512 of accumulator column ic
-    if (!fwd_role) {
+    if (inv_role) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             own_lo[r] = acc[ic * kN + ((r << 6) | lane)];
@@ -1295,7 +1297,7 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
 #pragma unroll
         for (int q = 0; q < 4; q++) dq[q * 64] = u32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
     };
-    if (!fwd_role && nact > 0) prepare_column(__builtin_amdgcn_readfirstlane(act[0]) & 0xffff);
+    if (inv_role && nact > 0) prepare_column(__builtin_amdgcn_readfirstlane(act[0]) & 0xffff);
     // The 2l x 2 products of a CMux are accumulated exactly as the throughput kernel does it (cmux_fast: one FMA chain per
     // spectrum value and column over the rows w = 0..2l-1 in order, starting from zero), so that a gate gives the same
     // ciphertext whichever kernel its batch size selects.  The chains are spread over ALL waves: unit u = (slice q = u & 7
@@ -1399,6 +1401,16 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
             if (nxt) load_mac_keys(kb, nxt >> 16);  // arrives during the inverse transforms
             __syncthreads();  // next differences in place; the inverse waves are done with the scratch
             TR(3)
+        }
+    } else if (kCoopFastWaves > kKpl + 2 && !inv_role) {  // helper wave: products only
+#pragma unroll 1
+        for (int pos = 0; pos < nact; pos++) {
+            const int nxt = pos + 1 < nact ? __builtin_amdgcn_readfirstlane(act[pos + 1]) : 0;
+            __syncthreads();
+            mac_units(kb);
+            __syncthreads();
+            if (nxt) load_mac_keys(kb, nxt >> 16);
+            __syncthreads();
         }
     } else {
 #pragma unroll 1
