@@ -244,6 +244,9 @@ __device__ __forceinline__ void mac_col(c64 (&acc)[8], const c64 (&v)[8], const 
 #define SKEW_PRIO_EXCHANGE() ((void) 0)
 #define SKEW_PRIO_COMPUTE() ((void) 0)
 #endif
+#ifndef TFHE_HIP_COOP_PREP
+#define TFHE_HIP_COOP_PREP 1  // A/B: FAST latency kernel prepares the next differences on all eight waves (a fourth barrier)
+#endif
 #ifndef TFHE_HIP_BARA_AHEAD
 #define TFHE_HIP_BARA_AHEAD 1  // A/B: gate kernels request the input coefficients of iteration i + 1 during iteration i
 #endif
@@ -1297,7 +1300,29 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
 #pragma unroll
         for (int q = 0; q < 4; q++) dq[q * 64] = u32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
     };
+#if TFHE_HIP_COOP_PREP
+    static_assert(kCoopFastWaves == 8, "one (column, quad) of the prepared differences per wave");
+    // the same words, spread over all eight waves: wave w prepares quad w & 3 of column w >> 2 (four coefficients per lane,
+    // one 16-byte store) from the accumulator mirror - a fourth barrier per CMux, but 1.1 k ticks less on the inverse
+    // waves, which are the critical path
+    auto prepare_quad = [&](int a) {
+        const int cq = wave >> 2, q = wave & 3;
+        const int32_t *col = acc + cq * kN;
+        uint32_t d[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int j = ((((q & 1) << 2) | i) << 6) | lane | ((q >> 1) << 9);
+            const int s = (j - a) & (2 * kN - 1);
+            const uint32_t v = (uint32_t) col[s & (kN - 1)];
+            const uint32_t rot = (s & kN) ? (0u - v) : v;
+            d[i] = decomp_prepare((int32_t) (rot - (uint32_t) col[j]));
+        }
+        reinterpret_cast<u32x4 *>(diff)[(cq * 4 + q) * 64 + lane] = u32x4{d[0], d[1], d[2], d[3]};
+    };
+    if (nact > 0) prepare_quad(__builtin_amdgcn_readfirstlane(act[0]) & 0xffff);
+#else
     if (inv_role && nact > 0) prepare_column(__builtin_amdgcn_readfirstlane(act[0]) & 0xffff);
+#endif
     // The 2l x 2 products of a CMux are accumulated exactly as the throughput kernel does it (cmux_fast: one FMA chain per
     // spectrum value and column over the rows w = 0..2l-1 in order, starting from zero), so that a gate gives the same
     // ciphertext whichever kernel its batch size selects.  The chains are spread over ALL waves: unit u = (slice q = u & 7
@@ -1399,7 +1424,11 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
             TR(2)
             __syncthreads();  // sums in place
             if (nxt) load_mac_keys(kb, nxt >> 16);  // arrives during the inverse transforms
-            __syncthreads();  // next differences in place; the inverse waves are done with the scratch
+#if TFHE_HIP_COOP_PREP
+            __syncthreads();  // accumulator mirror updated; the inverse waves are done with the scratch
+            if (nxt) prepare_quad(nxt & 0xffff);
+#endif
+            __syncthreads();  // next differences in place
             TR(3)
         }
     } else if (kCoopFastWaves > kKpl + 2 && !inv_role) {  // helper wave: products only
@@ -1410,6 +1439,10 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
             mac_units(kb);
             __syncthreads();
             if (nxt) load_mac_keys(kb, nxt >> 16);
+#if TFHE_HIP_COOP_PREP
+            __syncthreads();
+            if (nxt) prepare_quad(nxt & 0xffff);
+#endif
             __syncthreads();
         }
     } else {
@@ -1458,9 +1491,15 @@ __global__ __launch_bounds__(64 * kCoopFastWaves) void k_blind_rotate_coop_fast(
                 dst[((r << 6) | lane) + kNh] = own_hi[r];
             }
             TR(5)
+#if TFHE_HIP_COOP_PREP
+            __syncthreads();  // both columns of the mirror are current
+            if (nxt) {
+                prepare_quad(nxt & 0xffff);
+#else
             if (nxt) {
                 wave_sync();
                 prepare_column(nxt & 0xffff);
+#endif
                 // this wave's key values of the next CMux: requested only now, when the forward waves' requests (issued
                 // after the second barrier, 72 KB through the CU's one vector-memory pipe) have drained - issued next to
                 // them they queue behind them and hold up the inverse transform, which is the critical path
