@@ -1174,16 +1174,16 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_blind_rotate_coop(BrArgs A)
 
 // ---------------------------------------------------------------------------------------------------------------
 // latency shape in the FAST arithmetic mode: one ciphertext per workgroup of 2l forward waves + one inverse wave per
-// accumulator column, with the folded transforms of fast_core.h.  Per CMux, three workgroup barriers:
+// accumulator column, with the folded transforms of fast_core.h.  Per CMux, four workgroup barriers:
 //   forward wave w: digits of decomposition row w (from the prepared differences), forward transform, spectrum into its
 //                   LDS buffer                                                                           -> barrier
 //   every wave:     its share of the 2 x 512 FMA chains over the 2l rows (spectra from LDS x key values requested one CMux
 //                   ahead), in the throughput kernel's order: a gate's ciphertext does not depend on which kernel its
 //                   batch size selects; sums into the column's sum buffer                                -> barrier
-//   inverse waves:  inverse transform of their column's sums (512 points, one wave), accumulator update, and - the column
-//                   being theirs alone - its rotated, prepared differences for the next CMux (measured: the forward waves
-//                   gathering them for themselves moves the same 1.1 k ticks onto the six forward waves, two of which
-//                   share a SIMD: 2.22 against 2.05 ms per gate)                                         -> barrier
+//   inverse waves:  inverse transform of their column's sums (512 points, one wave), accumulator update  -> barrier
+//   every wave:     one (column, quad) of the rotated, prepared differences of the next CMux from the accumulator mirror
+//                   (TFHE_HIP_COOP_PREP; before: each inverse wave its whole column, 2.08 against 1.94 ms per gate; the
+//                   forward waves gathering all of theirs for themselves: 2.22 ms)                        -> barrier
 // Key values of the next CMux: forward waves request theirs after the second barrier, inverse waves at the end of theirs.
 // Rotations by 0 are skipped through a list of the non-zero rotation amounts built once per launch.  The twiddles of
 // both directions stay in registers (one ciphertext per CU: registers are not the constraint here).
