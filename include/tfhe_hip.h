@@ -107,7 +107,7 @@ const char *tfhe_hip_last_error(void);
  *          decorrelate, as for any two FFT implementations (tests/test_fast_mode.py).  Keyswitch and all integer
  *          stages stay exact.  About 1.5x the gate throughput; a single gate in 2.1 ms instead of 3.0 ms.  Results are
  *          deterministic and independent of the position in the batch AND of the batch size: the latency kernel (batches
- *          of up to 512 bootstraps) accumulates the 2l row products in the throughput kernel's order, so a gate gives the
+ *          of up to 768 bootstraps; 512 with the 80-bit set) accumulates the 2l row products in the throughput kernel's order, so a gate gives the
  *          same ciphertext in a batch of 1 and of 16,384, and a netlist the same pool at every level width.
  * The call waits for the context's stream; with keys loaded it derives the FAST key (a re-indexing of the same
  * doubles, 62 MB more device memory). */

@@ -206,12 +206,12 @@ def test_full_batch_16384_bits_identical(fast, engine, client, keys):
           % (np.log2(err.std()), np.log2(err_r.std())))
     assert 0.9 < err.std() / err_r.std() < 1.1
     again = fast.gate_batch(Gate.NAND, ca[5000:5600], cb[5000:5600])       # deterministic and position independent
-    assert np.array_equal(again, got[5000:5600])                           # (within the throughput kernels: above 512 gates)
+    assert np.array_equal(again, got[5000:5600])                           # (the latency kernel, 600 gates, against the throughput kernel)
 
 
 def test_latency_kernel_one_cmux_within_4_lsb(fast, oracle, okeys):
-    """batches of up to 512 run the one-workgroup-per-ciphertext kernel (k_blind_rotate_coop_fast): the same folded
-    transforms, the six row products summed after the multiplication instead of accumulated by FMA"""
+    """batches of up to 768 run the one-workgroup-per-ciphertext kernel (k_blind_rotate_coop_fast): the same folded
+    transforms, the six row products accumulated as one FMA chain per spectrum value, in the throughput kernel's order"""
     rng = np.random.default_rng(23)
     cnt = 9
     acc = rng.integers(-2**31, 2**31, (cnt, 2, P.N)).astype(np.int32)

@@ -110,7 +110,7 @@ def test_32bit_circuits_fast_wide_levels(kind, fast, client, keys):
     want_bits = plain_wires(nl, x, y, xs, ys, nbits)
     levels = nl.level_arrays(instances=W)
     widths = [int((lv[:, 0] < int(Gate.MUX)).sum() + 2 * (lv[:, 0] == int(Gate.MUX)).sum()) for lv in levels]
-    assert max(widths) > 512 and min(w for w in widths if w) <= 512
+    assert max(widths) > 768 and min(w for w in widths if w) <= 768     # both the throughput and the latency kernel
     d_a, d_b = fast.dev_alloc(pool.nbytes), fast.dev_alloc(pool.nbytes)
     try:
         fast.to_dev(d_a, pool)
@@ -297,7 +297,7 @@ def test_chained_soak_fast(fast, client, keys):
 
 
 def test_fast_results_do_not_depend_on_the_batch_size(fast, client, keys):
-    """the latency kernel (batches up to 512: one workgroup per ciphertext) accumulates the row products in the throughput
+    """the latency kernel (batches up to 768: one workgroup per ciphertext) accumulates the row products in the throughput
     kernel's order (one FMA chain per spectrum value over the rows), so a gate's ciphertext is the same in a batch of 1, 9,
     600 or 2,100 - e.g. the same circuit at level widths 400 and 600"""
     rng = np.random.default_rng(808)
@@ -306,7 +306,7 @@ def test_fast_results_do_not_depend_on_the_batch_size(fast, client, keys):
     ct = [client.encrypt(keys, bits[i], 2700 + i) for i in range(3)]
     big = fast.gate_batch(Gate.MUX, *ct)                               # 2,048 in the 8-wave kernel + 52 in the latency kernel
     assert np.array_equal(client.decrypt(keys, big)[0], np.where(bits[0] == 1, bits[1], bits[2]))
-    for lo, n in ((0, 1), (5, 9), (100, 400), (300, 600), (1000, 1024)):
+    for lo, n in ((0, 1), (5, 9), (100, 400), (300, 600), (200, 800), (1000, 1024)):
         part = fast.gate_batch(Gate.MUX, ct[0][lo:lo + n], ct[1][lo:lo + n], ct[2][lo:lo + n])
         assert np.array_equal(part, big[lo:lo + n]), (lo, n)
     x = ct[0][:700]

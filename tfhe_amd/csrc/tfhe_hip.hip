@@ -2672,9 +2672,10 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0, const c64 *custom_bk = nullptr)
     // (measured, default set, ms for 256 / 512 / 768 / 1024 / 1536 gates: latency kernel 3.3 / 6.1 / 9.0 / 12.0 / 18.0,
     //  4 waves per workgroup 9.5 / 9.6 / 9.7 / 9.8 / 19.6, 8 waves 13.9 / 14.0 / 14.1 / 14.2 / 14.2; tools/shape_bench.py)
     constexpr long long kCoopMax = kCoopWaves > 4 ? 768 : 512;  // rounds of 256 workgroups that still beat 4 waves
-    // FAST mode (ms for 256 / 512 / 768 / 1024 gates, tools/lat_time.py: latency kernel 2.2 / 4.4 / 6.5 / 8.7, one wave
-    // per workgroup 5.6 / 6.0 / 6.3 / 6.4, four waves 6.4 / 6.4 / 6.5 / 6.5): two rounds of workgroups
-    const long long coop_max = c->arith == TFHE_HIP_ARITH_FAST ? 512 : kCoopMax;
+    // FAST mode (round 3, ms for 256 / 512 / 768 / 1024 gates, tools/lat_time.py: latency kernel 2.15 / 3.9 / 5.8 / 7.7, one
+    // wave per workgroup 5.4 / 5.7 / 6.1 / 6.1, four waves 6.1 / 6.2 / 6.2 / 6.2, eight 8.7): up to three rounds of
+    // workgroups with the default set (the 80-bit set's throughput shapes are faster from two rounds on)
+    const long long coop_max = c->arith == TFHE_HIP_ARITH_FAST ? (kCoopWaves > 4 ? 768 : 512) : kCoopMax;
     if (waves == 0)
         waves = MODE == MODE_EXTMUL ? (A.B <= 256 ? 1 : A.B <= 1024 ? 4 : 8)
                                     : (A.B <= coop_max ? kShapeCoop : A.B <= 1024 ? 4 : 8);
