@@ -589,7 +589,7 @@ def main():
         hs = summary(head)
         traffic = None
         tr_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr_file) and PR.lam == 128:
+        if os.path.exists(tr_file) and PR.lam == 128 and B == 16384:   # the counters were collected on this workload only
             with open(tr_file) as f:
                 tj = json.load(f)
                 traffic = tj.get("k_blind_rotate_%s_hbm_bytes_per_launch" % head, tj.get("k_blind_rotate_hbm_bytes_per_launch"))
