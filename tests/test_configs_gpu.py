@@ -266,3 +266,19 @@ def test_group_netlist_levels_equal_single_context(mode, engine, fast, client, k
     assert np.array_equal(got, xs + ys)
     le, _ = client.decrypt(keys, want[(base + np.array(nl.outputs["le"])[None, :]).reshape(-1)])
     assert np.array_equal(le.reshape(-1), (xs <= ys).astype(np.uint8))
+
+
+def test_damaged_key_broadcast_is_detected_and_replaced():
+    """the verified key broadcast: rank 1 damages eight bytes of what it received (failure injection in
+    parallel.broadcast_keys_device); the fingerprints differ, every rank reports "host", bench.py redistributes the keys
+    through host memory and the run's outputs still decrypt correctly on both ranks"""
+    import json
+    env = dict(os.environ, TFHE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", TFHE_TEST_CORRUPT_KEYS_RANK="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--batch", "600", "--no-cpu-baseline", "--arith", "fast"], env=env, capture_output=True, text=True,
+                       timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["keys_via"] == "host" and line["config"]["outputs_decrypt_correctly"]
+    assert "falling back to the host path" in r.stderr

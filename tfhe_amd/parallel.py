@@ -8,6 +8,8 @@ independent in the reference: the gates of one batch / one netlist level.
   * gates shard in contiguous blocks, no collective on the data path,
   * results are all-gathered only when the caller needs the whole array on every rank (next level of a netlist).
 """
+import os
+
 import numpy as np
 
 from .client import KeySet
@@ -105,6 +107,10 @@ def broadcast_keys_device(engine, src=0, verify=False, device=None):
                 dist.broadcast(h, src=src)
                 if dist.get_rank() != src:
                     t.copy_(h)
+            # failure injection for the tests: the named rank damages what it received, so that the verification below
+            # has something to find (TFHE_TEST_CORRUPT_KEYS_RANK; never set in production)
+            if os.environ.get("TFHE_TEST_CORRUPT_KEYS_RANK") == str(dist.get_rank()) and dist.get_rank() != src:
+                t[:8] ^= 0x55
         torch.cuda.synchronize()
     except Exception as e:                               # noqa: BLE001 - any failure here means "use the host path"
         if not verify:
