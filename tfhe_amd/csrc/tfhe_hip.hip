@@ -2676,9 +2676,12 @@ int launch_br(tfhe_hip_ctx *c, const BrArgs &A0, const c64 *custom_bk = nullptr)
     // wave per workgroup 5.4 / 5.7 / 6.1 / 6.1, four waves 6.1 / 6.2 / 6.2 / 6.2, eight 8.7): up to three rounds of
     // workgroups with the default set (the 80-bit set's throughput shapes are faster from two rounds on)
     const long long coop_max = c->arith == TFHE_HIP_ARITH_FAST ? (kCoopWaves > 4 ? 768 : 512) : kCoopMax;
+    // 769..1,024 gates: FAST with the default set runs one wave per workgroup (6.06 against 6.23 ms with four; EXACT at
+    // one wave per workgroup keeps only 768 ciphertexts resident: 18.5 against 9.9 ms)
+    const int mid_shape = c->arith == TFHE_HIP_ARITH_FAST && kCoopWaves > 4 ? 1 : 4;
     if (waves == 0)
         waves = MODE == MODE_EXTMUL ? (A.B <= 256 ? 1 : A.B <= 1024 ? 4 : 8)
-                                    : (A.B <= coop_max ? kShapeCoop : A.B <= 1024 ? 4 : 8);
+                                    : (A.B <= coop_max ? kShapeCoop : A.B <= 1024 ? mid_shape : 8);
     if (waves == kShapeCoop && MODE != MODE_EXTMUL && c->arith == TFHE_HIP_ARITH_FAST) {  // latency shape, FAST arithmetic
         A.tw = c->twf;
         A.bk = custom_bk ? custom_bk : c->bkf;
